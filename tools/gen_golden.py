@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz -- runs ONLY in the authoring container.
+
+Pins the CPU oracle (oracle/vit_oracle.py, oracle/resnet_oracle.py) to the real thing:
+  * ViT:    HuggingFace ``ViTForImageClassification`` built from a LOCAL ``ViTConfig``
+            (no download) -- the third-party library TIC/ViT/model.py:2,27-45 delegates to
+            (transformers 5.15.0 as installed; the reference pins no version).
+  * ResNet: the reference's own TIC/ResNet/model.py imported from /root/reference.
+The fixtures are DATA (inputs, weights for the tiny configs, expected outputs); no
+reference source text is stored.  Usage:  python tools/gen_golden.py [vit|resnet|all]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+from oracle import vit_oracle as vo  # noqa: E402
+
+
+def hf_model(spec: vo.ViTSpec, params):
+    from transformers import ViTConfig, ViTForImageClassification
+    cfg = ViTConfig(hidden_size=spec.hidden, num_hidden_layers=spec.layers, num_attention_heads=spec.heads,
+                    intermediate_size=spec.mlp, num_labels=spec.num_labels, image_size=spec.image,
+                    patch_size=spec.patch, num_channels=spec.channels)
+    m = ViTForImageClassification(cfg)
+    missing, unexpected = m.load_state_dict(params, strict=True)
+    assert not missing and not unexpected
+    return m.train()   # dropouts are 0.0 -> train() == eval() numerically
+
+
+def hf_run(m, x, target):
+    m.zero_grad()
+    logits = m(x).logits
+    loss = torch.nn.functional.cross_entropy(logits, target)
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    return logits.detach(), loss.detach(), grads
+
+
+def gen_vit_tiny():
+    spec = vo.ViTSpec(**vo.VIT_TINY, num_labels=10)
+    params = vo.randomize_small_params(vo.init_params(spec, seed=0), seed=1)
+    g = torch.Generator().manual_seed(1234)
+    B = 4
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, spec.num_labels, (B,), generator=g)
+    soft = torch.softmax(torch.randn(B, spec.num_labels, generator=g) * 2, -1)
+    m = hf_model(spec, params)
+    out = {"x": x.numpy(), "y": y.numpy(), "soft": soft.numpy()}
+    for tag, tgt in (("hard", y), ("soft", soft)):
+        logits, loss, grads = hf_run(m, x, tgt)
+        o_logits, o_loss, o_grads = vo.loss_and_grads(params, x, tgt, spec)
+        err = (logits - o_logits).abs().max().item()
+        gerr = max((grads[k] - o_grads[k]).abs().max().item() for k in grads)
+        print(f"[vit tiny/{tag}] oracle-vs-HF  logits max|d|={err:.2e}  loss d={abs(loss - o_loss).item():.2e}  grads max|d|={gerr:.2e}")
+        assert err < 1e-5 and gerr < 1e-5
+        out[f"logits_{tag}"] = logits.numpy()
+        out[f"loss_{tag}"] = np.float32(loss.item())
+        for k, v in grads.items():
+            if tag == "hard":
+                out[f"grad_{tag}/{k}"] = v.numpy()
+            else:
+                out[f"gradnorm_{tag}/{k}"] = np.float64(v.norm().item())
+    # one AdamW step with torch.optim.AdamW (ntrain.py:39-41 hyper-parameters), hard labels
+    m.zero_grad()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-5, weight_decay=0.01)
+    torch.nn.functional.cross_entropy(m(x).logits, y).backward()
+    opt.step()
+    for k, p in m.named_parameters():
+        out[f"after_adamw/{k}"] = p.detach().numpy().copy()
+    for k, v in params.items():
+        out[f"param/{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(GOLD, "vit_tiny.npz"), **out)
+
+
+def gen_vit_full(tag, base, C, B, seed):
+    """Full-size B/L: weights are regenerated from the seed on both sides -> store only
+    logits / loss / top-k / per-parameter gradient L2 norms."""
+    spec = vo.ViTSpec(**base, num_labels=C)
+    params = vo.randomize_small_params(vo.init_params(spec, seed=seed), seed=seed + 1)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    m = hf_model(spec, params)
+    logits, loss, grads = hf_run(m, x, y)
+    o_logits, o_loss, o_grads = vo.loss_and_grads(params, x, y, spec)
+    err = (logits - o_logits).abs().max().item()
+    gn = {k: v.norm().item() for k, v in grads.items()}
+    gmax = max(gn.values())   # k_proj.bias has an analytically zero gradient -> compare against the global scale
+    gn_err = max(abs(gn[k] - o_grads[k].norm().item()) / (gn[k] + 1e-4 * gmax) for k in gn)
+    print(f"[vit {tag}] oracle-vs-HF logits max|d|={err:.2e} loss d={abs(loss - o_loss).item():.2e} grad-norm rel={gn_err:.2e}")
+    assert err < 2e-5 and gn_err < 1e-4
+    names = list(gn.keys())
+    np.savez_compressed(os.path.join(GOLD, f"vit_{tag}.npz"), seed=seed, B=B, C=C,
+                        y=y.numpy(), logits=logits.numpy(), loss=np.float32(loss.item()),
+                        top1=logits.argmax(-1).numpy(), top5=logits.topk(min(5, C), -1).indices.numpy(),
+                        grad_norm_names=np.array(names), grad_norms=np.array([gn[k] for k in names], np.float64),
+                        x_checksum=np.float64(x.double().sum().item()))
+
+
+def gen_resnet():
+    sys.path.insert(0, "/root/reference")
+    from TIC.ResNet import model as ref   # reference file, torch only
+    from oracle import resnet_oracle as ro
+    for name, B, C, img, full in (("resnet18", 2, 10, 64, True), ("resnet50", 4, 10, 224, False)):
+        torch.manual_seed(0)
+        m = getattr(ref, name)(num_classes=C).train()
+        # non-trivial BN affine so gamma/beta paths are exercised
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if p.ndim == 1:
+                    p.add_(torch.empty_like(p).normal_(0, 0.05, generator=g))
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        x = torch.randn(B, 3, img, img, generator=g)
+        y = torch.randint(0, C, (B,), generator=g)
+        logits = m(x)
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        after = {k: v.detach().clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+        o_logits, o_loss, o_grads, o_after = ro.loss_and_grads(sd, x, y, name)
+        err = (logits.detach() - o_logits).abs().max().item()
+        gerr = max((grads[k] - o_grads[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-12) for k in grads)
+        rerr = max((after[k].float() - o_after[k].float()).abs().max().item() for k in after)
+        print(f"[{name}] oracle-vs-reference logits max|d|={err:.2e} grads rel={gerr:.2e} running-stats d={rerr:.2e}")
+        assert err < 1e-4 and gerr < 1e-3 and rerr < 1e-5
+        out = {"x": x.numpy(), "y": y.numpy(), "logits": logits.detach().numpy(), "loss": np.float32(loss.item())}
+        names = list(grads.keys())
+        out["grad_norm_names"] = np.array(names)
+        out["grad_norms"] = np.array([grads[k].norm().item() for k in names], np.float64)
+        for k, v in after.items():
+            out[f"after/{k}"] = v.numpy()
+        if full:
+            for k, v in sd.items():
+                out[f"state/{k}"] = v.numpy()
+            for k, v in grads.items():
+                out[f"grad/{k}"] = v.numpy()
+        else:
+            out["seed_note"] = np.array("weights = reference init under torch.manual_seed(0) + N(0,.05) on 1-D params (gen 7); stored as state/ for 1-D only")
+            for k, v in sd.items():
+                out[f"state/{k}"] = v.numpy().astype(np.float16) if v.ndim == 4 else v.numpy()
+        np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    torch.set_num_threads(8)
+    if what in ("vit", "all"):
+        gen_vit_tiny()
+        gen_vit_full("base_c10_b4", vo.VIT_BASE, 10, 4, seed=10)
+        gen_vit_full("large_c120_b2", vo.VIT_LARGE, 120, 2, seed=20)
+    if what in ("resnet", "all"):
+        gen_resnet()
