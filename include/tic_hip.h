@@ -1,0 +1,150 @@
+/* tic_hip.h -- C ABI of libtic_hip.so: the MI355X (gfx950) hot path of the TIC ViT fine-tune step.
+ *
+ * The reference (fAKe2004/TouhouImageClassification) has no FFI: its hot path is the chain of
+ * torch/cuBLAS/cuDNN kernels reached from `model(x)` / `loss.backward()` / `optimizer.step()`
+ * (TIC/ViT/finetune.py:54-67, TIC/ViT/ntrain.py:43-50).  Each entry point below replaces one of
+ * those vendor-kernel families; the citation names the reference-side call it stands in for
+ * (HF = transformers/models/vit/modeling_vit.py, the library TIC/ViT/model.py:2,27-45 delegates to).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the CALLER owns every buffer (the library never allocates or
+ *     frees device memory and keeps no mutable global state besides the last-error string);
+ *   - every call enqueues asynchronously on `stream` (a hipStream_t; pass torch's current stream)
+ *     and returns 0, or a negative TIC_E* code with tic_last_error_string() set;
+ *   - bf16 tensors are raw 16-bit storage (`void*`), fp32 tensors `float*`, all contiguous
+ *     row-major, 16-byte aligned; "tokens" matrices are [M, D] with M = B * N (N = 197).
+ */
+#ifndef TIC_HIP_H
+#define TIC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tic_stream_t; /* hipStream_t */
+
+#define TIC_OK 0
+#define TIC_EINVAL (-1)  /* bad shape / alignment / null pointer */
+#define TIC_ELAUNCH (-2) /* HIP launch error */
+
+#define TIC_ABI_VERSION 1
+int tic_version(void);
+const char* tic_last_error_string(void);
+
+/* GEMM epilogues (fused into the MFMA kernel's store) */
+#define TIC_EPI_BF16 0  /* out = bf16(acc + bias)                                   Linear            */
+#define TIC_EPI_GELU 1  /* out = u = bf16(acc + bias); out2 = bf16(gelu_erf(u))     fc1 + GELU        */
+#define TIC_EPI_RESID 2 /* out_f32 = resid + bf16(acc + bias)                       o_proj / fc2 + residual */
+#define TIC_EPI_DGELU 3 /* out = bf16(bf16(acc) * gelu'(aux))                       backward through GELU */
+#define TIC_EPI_PATCH 4 /* out_f32[(m/P)*(P+1)+1+m%P] = bf16(acc+bias) + rowtab[1+m%P]   patch embed + pos */
+
+/* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  N % 128 == 0, K % 64 == 0, any M >= 1.
+ * Replaces nn.Linear forward (HF:202-205,216-218,235-236,246-247,250-252) and, fed with W^T, the dX half
+ * of its backward; EPI_PATCH replaces the patch Conv2d + position add (HF:60,69,146-157). */
+int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
+                     void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
+                     const void* aux_bf16, const float* rowtab, int patches, tic_stream_t stream);
+
+/* C[N,K] += A[M,N]^T . B[M,K]  (fp32 accumulate into C; C holds the running gradient).
+ * N % 128 == 0, K % 128 == 0.  Replaces the dW half of nn.Linear backward (autograd, finetune.py:62). */
+int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, tic_stream_t stream);
+
+/* LayerNorm(eps) over the last dim of fp32 rows -> bf16; saves mean / rstd.  in_stride = elements
+ * between consecutive input rows (D for the token stream, N*D to pick the CLS rows).  HF:261-262,274,281,385. */
+int tic_layernorm_fwd(const float* x, long in_stride, const float* gamma, const float* beta, void* y_bf16,
+                      float* mean, float* rstd, int rows, int D, float eps, tic_stream_t stream);
+/* dx = (dres ? dres : 0) + LN'(dy); also writes bf16(dx) to dxb (optional); dgamma/dbeta += . */
+int tic_layernorm_bwd(const void* dy_bf16, const float* x, long stride, const float* gamma, const float* mean,
+                      const float* rstd, const float* dres, float* dx, void* dxb_bf16, float* dgamma,
+                      float* dbeta, int rows, int D, tic_stream_t stream);
+
+/* softmax(q k^T * scale) v per (image, head); qkv packed [M, 3D], head_dim 64, N <= 208.
+ * Replaces F.scaled_dot_product_attention (HF:220-233) and its backward. lse: [B*H, N] fp32. */
+int tic_attention_fwd(const void* qkv, void* o, float* lse, int B, int H, int N, float scale, tic_stream_t stream);
+int tic_attention_bwd(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, int B,
+                      int H, int N, float scale, tic_stream_t stream);
+
+/* pixel_values [B,C,img,img] fp32 -> patch matrix [B*(img/patch)^2, C*patch*patch] bf16 (HF:60,69) */
+int tic_patchify(const float* x, void* P_bf16, int B, int C, int img, int patch, tic_stream_t stream);
+/* h[b,0,:] = cls + pos[0,:]  (HF:146-157);  backward: dcls, dpos += sum_b dh */
+int tic_embed_cls(const float* cls, const float* pos, float* h, int B, int N, int D, tic_stream_t stream);
+int tic_embed_bwd(const float* dh, float* dcls, float* dpos, int B, int N, int D, tic_stream_t stream);
+/* out_bf16[b*(N-1)+p, :] = bf16(dh[b, 1+p, :]) : token-stream gradient -> patch rows */
+int tic_gather_patch_rows(const float* dh, void* out_bf16, int B, int N, int D, tic_stream_t stream);
+
+/* out[n] += sum_m in[m,n]  (bias gradients) */
+int tic_colsum_bf16(const void* in_bf16, float* out, int M, int N, tic_stream_t stream);
+/* fp32 -> bf16 (n % 4 == 0) and fp32 [R,C] -> bf16 [C,R] (R, C % 64 == 0): autocast's weight casts */
+int tic_cast_bf16(const float* in, void* out_bf16, long n, tic_stream_t stream);
+int tic_cast_transpose_bf16(const float* in, void* out_bf16, int R, int C, tic_stream_t stream);
+
+/* torch.optim.AdamW step over a flat fp32 buffer (n % 4 == 0), step is 1-based; optional bf16 shadow.
+ * Replaces optimizer.step() with AdamW(lr, weight_decay) on every parameter (ntrain.py:39-41, finetune.py:314). */
+int tic_adamw(float* p, const float* g, float* m, float* v, void* w16_or_null, long n, float lr, float beta1,
+              float beta2, float eps, float weight_decay, int step, tic_stream_t stream);
+
+/* classifier on the CLS rows (HF:559-561): logits fp32 (bf16-rounded) = z . W^T + b ; and its backward */
+int tic_head_fwd(const void* z_bf16, const float* W, const float* bias, float* logits, int B, int C, int D,
+                 tic_stream_t stream);
+int tic_head_bwd(const float* dlogits, const void* z_bf16, const float* W, void* dz_bf16, float* dW, float* db,
+                 int B, int C, int D, tic_stream_t stream);
+
+/* mean cross-entropy; labels (int64 [B]) XOR soft ([B,C] fp32).  *loss_sum += loss (zero it first);
+ * dlogits (optional) = gscale * dloss/dlogits.  finetune.py:61,315; ntrain.py:48,55. */
+int tic_softmax_xent(const float* logits, const int64_t* labels, const float* soft, float* loss_sum,
+                     float* dlogits, int B, int C, float gscale, tic_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-model step: one call enqueues every kernel of a phase (no per-op Python on the hot path).
+ * Parameters, gradients, AdamW state and bf16 shadows live in caller-owned FLAT buffers with the
+ * canonical layout returned by tic_vit_layout(); activations live in one caller-owned workspace.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int B;      /* images per call (per GPU) */
+    int D, H, F, L, C; /* hidden, heads, mlp, layers, classes */
+    int img, patch, chans;
+    float eps;
+} TicVitDims;
+
+typedef struct {
+    /* element offsets into the flat fp32 parameter / gradient / AdamW buffers (and the bf16 shadow) */
+    long cls, pos, patch_w, patch_b;
+    long layer0, layer_stride;                 /* layer l block starts at layer0 + l*layer_stride */
+    long ln1_g, ln1_b, wqkv, bqkv, wo, bo, ln2_g, ln2_b, w1, b1, w2, b2; /* offsets inside a layer block */
+    long lnf_g, lnf_b, cls_w, cls_b;
+    long n_params;                             /* total elements (padded, multiple of 8) */
+    /* element offsets into the bf16 transposed-weight buffer */
+    long t_layer_stride, t_wqkv, t_wo, t_w1, t_w2, t_total;
+    /* byte offsets into the activation workspace */
+    size_t P, hs, hs_stride, layer_ws, layer_ws_stride;
+    size_t a1, mean1, rstd1, qkv, lse, o, hmid, a2, mean2, rstd2, u, g; /* inside a layer_ws block */
+    size_t zf, meanf, rstdf, logits, dlogits, dzf, dh, dhb, du, da, dqkv, dpatch;
+    size_t ws_bytes;
+} TicVitLayout;
+
+int tic_vit_layout(const TicVitDims* dims, TicVitLayout* out);
+
+typedef struct {
+    TicVitDims dims;
+    float* params;        /* fp32 master weights          [n_params] */
+    float* grads;         /* fp32 gradients               [n_params] */
+    void* w16;            /* bf16 shadow of params        [n_params] */
+    void* wT16;           /* bf16 transposed GEMM weights [t_total]  */
+    void* workspace;      /* ws_bytes */
+} TicVitState;
+
+/* refresh w16 / wT16 from params (after load_state_dict or an external optimizer step) */
+int tic_vit_refresh_weights(const TicVitState* st, tic_stream_t stream);
+/* pixel_values [B,3,224,224] fp32 -> logits [B,C] fp32 (also kept in the workspace) */
+int tic_vit_forward(const TicVitState* st, const float* pixel_values, float* logits_out, tic_stream_t stream);
+/* backward in three phases so the caller can overlap gradient all-reduce per bucket:
+ *   head (classifier + final LN), layer l = L-1 .. 0, embeddings.  grads are ACCUMULATED into st->grads. */
+int tic_vit_backward_head(const TicVitState* st, const float* dlogits, tic_stream_t stream);
+int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stream_t stream);
+int tic_vit_backward_embed(const TicVitState* st, tic_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIC_HIP_H */

@@ -1,0 +1,12 @@
+// tic_sim.cpp -- TEST INFRASTRUCTURE: the C ABI of include/tic_hip.h compiled against the CPU
+// wave-lockstep simulator (sim_runtime.h) instead of gfx950.  Pointers are host pointers.  Used by
+// tests/test_sim_*.py to check lane maps, LDS swizzles and range-check handling of the kernel
+// sources on tiny shapes without a GPU.  Never loaded by the product package.
+#define TIC_SIM 1
+#include <math.h>
+#include <string.h>
+#define TIC_RT_LAST_ERROR() ((const char*)nullptr)
+#define TIC_RT_MEMSET(p, v, n, s) memset((p), (v), (n))
+#define TIC_RT_MEMCPY(d, src, n, s) memcpy((d), (src), (n))
+#define TIC_RT_MAX_LDS(kernel, bytes) do { } while (0)
+#include "../../touhouimageclassification_amd/csrc/tic_api_impl.h"

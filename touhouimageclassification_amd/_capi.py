@@ -1,0 +1,83 @@
+"""ctypes signatures for the C ABI declared in include/tic_hip.h.
+
+`bind(lib)` attaches argtypes/restype to every exported symbol and returns the list of names, so
+the product loader (`_lib.py`, libtic_hip.so) and the test-only simulator loader (tests/sim) share
+one definition.  No torch types cross the boundary: pointers are integers (`tensor.data_ptr()`),
+the stream is the raw hipStream_t handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_long
+F = C.c_float
+SZ = C.c_size_t
+
+
+class TicVitDims(C.Structure):
+    _fields_ = [("B", I), ("D", I), ("H", I), ("F", I), ("L", I), ("C", I),
+                ("img", I), ("patch", I), ("chans", I), ("eps", F)]
+
+
+class TicVitLayout(C.Structure):
+    _fields_ = [(n, L) for n in (
+        "cls", "pos", "patch_w", "patch_b", "layer0", "layer_stride",
+        "ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2",
+        "lnf_g", "lnf_b", "cls_w", "cls_b", "n_params",
+        "t_layer_stride", "t_wqkv", "t_wo", "t_w1", "t_w2", "t_total")] + [(n, SZ) for n in (
+        "P", "hs", "hs_stride", "layer_ws", "layer_ws_stride",
+        "a1", "mean1", "rstd1", "qkv", "lse", "o", "hmid", "a2", "mean2", "rstd2", "u", "g",
+        "zf", "meanf", "rstdf", "logits", "dlogits", "dzf", "dh", "dhb", "du", "da", "dqkv", "dpatch",
+        "ws_bytes")]
+
+
+class TicVitState(C.Structure):
+    _fields_ = [("dims", TicVitDims), ("params", P), ("grads", P), ("w16", P), ("wT16", P), ("workspace", P)]
+
+
+SIGNATURES = {
+    "tic_version": ([], I),
+    "tic_last_error_string": ([], C.c_char_p),
+    "tic_gemm_nt_bf16": ([P, P, I, I, I, I, P, P, P, P, P, P, P, I, P], I),
+    "tic_gemm_tn_bf16": ([P, P, P, I, I, I, P], I),
+    "tic_layernorm_fwd": ([P, L, P, P, P, P, P, I, I, F, P], I),
+    "tic_layernorm_bwd": ([P, P, L, P, P, P, P, P, P, P, P, I, I, P], I),
+    "tic_attention_fwd": ([P, P, P, I, I, I, F, P], I),
+    "tic_attention_bwd": ([P, P, P, P, P, I, I, I, F, P], I),
+    "tic_patchify": ([P, P, I, I, I, I, P], I),
+    "tic_embed_cls": ([P, P, P, I, I, I, P], I),
+    "tic_embed_bwd": ([P, P, P, I, I, I, P], I),
+    "tic_gather_patch_rows": ([P, P, I, I, I, P], I),
+    "tic_colsum_bf16": ([P, P, I, I, P], I),
+    "tic_cast_bf16": ([P, P, L, P], I),
+    "tic_cast_transpose_bf16": ([P, P, I, I, P], I),
+    "tic_adamw": ([P, P, P, P, P, L, F, F, F, F, F, I, P], I),
+    "tic_head_fwd": ([P, P, P, P, I, I, I, P], I),
+    "tic_head_bwd": ([P, P, P, P, P, P, I, I, I, P], I),
+    "tic_softmax_xent": ([P, P, P, P, P, I, I, F, P], I),
+    "tic_vit_layout": ([C.POINTER(TicVitDims), C.POINTER(TicVitLayout)], I),
+    "tic_vit_refresh_weights": ([C.POINTER(TicVitState), P], I),
+    "tic_vit_forward": ([C.POINTER(TicVitState), P, P, P], I),
+    "tic_vit_backward_head": ([C.POINTER(TicVitState), P, P], I),
+    "tic_vit_backward_layer": ([C.POINTER(TicVitState), I, P], I),
+    "tic_vit_backward_embed": ([C.POINTER(TicVitState), P], I),
+}
+
+
+def bind(lib: C.CDLL):
+    for name, (args, res) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here == a declared symbol is not exported
+        fn.argtypes = args
+        fn.restype = res
+    return list(SIGNATURES)
+
+
+class TicError(RuntimeError):
+    pass
+
+
+def check(lib: C.CDLL, rc: int) -> None:
+    if rc != 0:
+        raise TicError(f"libtic error {rc}: {lib.tic_last_error_string().decode(errors='replace')}")

@@ -1,0 +1,296 @@
+// attention.h -- fused scaled-dot-product attention for N = 197 tokens, head_dim = 64 (gfx950).
+//
+// Replaces F.scaled_dot_product_attention (non-causal, no mask, dropout 0, scale 1/8) reached
+// from HF modeling_vit.py:220-233 (TIC/ViT/model.py:27-45) and its autograd backward.
+//
+// One workgroup (4 waves) owns one (image, head): the whole K and V of a head (197 x 64 bf16 =
+// 25 KiB each) sit in LDS, so attention is a single-tile problem -- no online-softmax loop, no
+// cross-workgroup reduction, deterministic.  Layout: packed qkv [M, 3D] bf16 (row = image*N + token;
+// q | k | v column blocks, head h at columns h*64 inside each), output o [M, D] bf16.
+//
+// Forward, per 16-query block (wave-private): S^T = K.Q^T on MFMA 16x16x32 with the QUERY on the
+// lane (lane&15), so a softmax row is spread over 4 lanes (2 shuffles), P never leaves registers
+// (the S^T accumulators are, after bf16 packing, exactly the B operand of O^T = V^T.P^T with a
+// permuted key order that the V^T fragment -- a ds_read_b64_tr_b16 of the row-major V tile --
+// reproduces), and O^T comes out with 4 consecutive d per lane (8-byte stores).
+//
+// Backward: phase A gives each wave a set of 16-key tiles and sweeps all queries with the KEY on the
+// lane (S and dP accumulators are directly the B operands of dV^T += dO^T.P and dK^T += Q^T.dS);
+// phase B gives each wave a set of 16-query blocks and sweeps all keys with the QUERY on the lane
+// (dS^T accumulators are the B operand of dQ^T += K^T.dS^T).  S and dP are computed twice (7 MFMA
+// products instead of 5) in exchange for no atomics, no LDS transposes and no cross-wave sums.
+#pragma once
+#include "gemm.h"   // swz128
+
+#define ATT_ROWS 224                     // keys/queries padded to 7 x 32
+#define ATT_TILE_BYTES (ATT_ROWS * 128)  // [224][64] bf16
+#define ATT_HD 64
+
+struct AttnParams {
+    const bf16_t* qkv;   // [M, 3D]
+    bf16_t* o;           // [M, D]        (fwd: out, bwd: in)
+    float* lse;          // [B*H, N]      (fwd: out, bwd: in)  natural-log-sum-exp of the scaled scores
+    const bf16_t* d_o;   // [M, D]        (bwd)
+    bf16_t* dqkv;        // [M, 3D]       (bwd out)
+    int B, H, N, D;      // D = H * 64
+    float scale;
+};
+
+// stage one [ATT_ROWS][64] bf16 tile (rows = tokens of image b, columns = col0..col0+63 of a
+// row-major [M, ld] bf16 matrix) into LDS at tile_off; rows >= N are zero-filled (forced
+// out-of-range offset).  28 one-KiB pieces, piece = i*4 + w.
+TIC_DEV void att_stage_tile(tic_rsrc_t r, uint32_t tile_off, long row0, int N, int ld, int col0, int l, int w) {
+    const uint32_t slot_log = (uint32_t)(l & 7) ^ ((((uint32_t)l >> 4) & 3u) << 1);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int piece = i * 4 + w;
+        const int row = piece * 8 + (l >> 3);
+        const uint32_t voff = (row < N) ? (uint32_t)((((size_t)(row0 + row)) * ld + col0 + slot_log * 8) * 2) : 0xFFFFFFF0u;
+        glds16(r, tile_off + (uint32_t)piece * 1024u, voff, 0);
+    }
+}
+
+// row-fragment (ds_read_b128) offset: tile row `row`, 16-B logical chunk `chunk`
+TIC_DEV uint32_t att_row_off(uint32_t row, uint32_t chunk) { return row * 128u + ((chunk ^ swz128(row)) * 16u); }
+// transposed-fragment (ds_read_b64_tr_b16) offset: tile row `row`, element column `col` (multiple of 4)
+TIC_DEV uint32_t att_tr_off(uint32_t row, uint32_t col) {
+    return row * 128u + (((col >> 3) ^ swz128(row)) * 16u) + (col & 4u) * 2u;
+}
+TIC_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+TIC_DEV bf16x8 pack8(f32x4 a, f32x4 b) {
+    return bf16x8{(short)f2bf(a[0]), (short)f2bf(a[1]), (short)f2bf(a[2]), (short)f2bf(a[3]),
+                  (short)f2bf(b[0]), (short)f2bf(b[1]), (short)f2bf(b[2]), (short)f2bf(b[3])};
+}
+
+// [row-major tile][kk <-> permuted row] transposed fragment for reduction block `blk32` (32 rows),
+// output tile dt (16 columns): lane (g = l>>4, q' = (l>>2)&3, p' = l&3) reads rows
+// 32*blk32 + 16*second + 4g + q', columns 16*dt + 4p'.
+TIC_DEV bf16x8 att_tr_frag(uint32_t tile_off, int blk32, int dt, int l) {
+    const uint32_t g = (uint32_t)l >> 4, qq = ((uint32_t)l >> 2) & 3u, pp = (uint32_t)l & 3u;
+    const uint32_t row = 32u * blk32 + 4u * g + qq, col = 16u * dt + 4u * pp;
+    const bf16x4 lo = lds_tr64(tile_off + att_tr_off(row, col));
+    const bf16x4 hi = lds_tr64(tile_off + att_tr_off(row + 16u, col));
+    return cat4(lo, hi);
+}
+
+__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
+    const int l = lane_id(), w = wave_id();
+    const int bh = TIC_BID_X, b = bh / p.H, h = bh - b * p.H;
+    const int N = p.N, D = p.D, ld = 3 * D;
+    const long row0 = (long)b * N;
+    const uint32_t KT = 0, VT = ATT_TILE_BYTES;
+    const tic_rsrc_t rq = make_rsrc(p.qkv, (uint32_t)((size_t)p.B * N * ld * 2));
+    att_stage_tile(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
+    att_stage_tile(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
+    wait_vmcnt0();
+    block_sync();
+
+    const int g = l >> 4, qi = l & 15;
+    const float c = p.scale * 1.4426950408889634f;
+    const float NEG_INF = -__builtin_huge_valf();
+    for (int qb = w; qb < 13; qb += 4) {
+        const int q = qb * 16 + qi;
+        // Q fragments (B operand of S^T = K.Q^T): query q, d = 32ks + 8g .. +7, straight from HBM
+        bf16x8 fq[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint32_t voff = (q < N) ? (uint32_t)((((size_t)(row0 + q)) * ld + h * ATT_HD + ks * 32 + g * 8) * 2) : 0xFFFFFFF0u;
+            const u32x4 raw = buf_ld128(rq, voff, 0);
+            fq[ks] = __builtin_bit_cast(bf16x8, raw);
+        }
+        f32x4 s[14];
+#pragma unroll
+        for (int kt = 0; kt < 13; ++kt) {
+            f32x4 a = f32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 fk = lds_ld128(KT + att_row_off((uint32_t)(kt * 16 + qi), (uint32_t)(ks * 4 + g)));
+                a = mfma16(fk, fq[ks], a);
+            }
+            s[kt] = a;   // keys kt*16 + 4g + r, query qi
+        }
+        // mask the padded keys of the last tile, row max over 4 lanes x 52 values
+        float mx = NEG_INF;
+#pragma unroll
+        for (int kt = 0; kt < 13; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kt * 16 + 4 * g + r >= N) s[kt][r] = NEG_INF;   // padded keys (only the last tile at N = 197)
+                mx = fmaxf(mx, s[kt][r]);
+            }
+        mx = fmaxf(mx, shfl_xor(mx, 16));
+        mx = fmaxf(mx, shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 13; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = fast_exp2((s[kt][r] - mx) * c);
+                s[kt][r] = e;
+                sum += e;
+            }
+        s[13] = f32x4{0, 0, 0, 0};
+        sum += shfl_xor(sum, 16);
+        sum += shfl_xor(sum, 32);
+        // O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kb = 0; kb < 7; ++kb) {
+            const bf16x8 fp = pack8(s[2 * kb], s[2 * kb + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = mfma16(att_tr_frag(VT, kb, dt, l), fp, oacc[dt]);
+        }
+        if (q < N) {
+            const float inv = 1.0f / sum;
+            bf16_t* orow = p.o + (size_t)(row0 + q) * D + h * ATT_HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<u32x2*>(orow + dt * 16) =
+                    u32x2{pack2bf(oacc[dt][0] * inv, oacc[dt][1] * inv), pack2bf(oacc[dt][2] * inv, oacc[dt][3] * inv)};
+            if (g == 0) p.lse[(size_t)bh * N + q] = mx * p.scale + __logf(sum);
+        }
+    }
+}
+
+// LDS: Q | K | V | dO tiles, then lse[224] and delta[224] floats
+#define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4)
+
+__global__ void __launch_bounds__(256, 1) attn_bwd_kernel(AttnParams p) {
+    const int l = lane_id(), w = wave_id(), tid = TIC_TID;
+    const int bh = TIC_BID_X, b = bh / p.H, h = bh - b * p.H;
+    const int N = p.N, D = p.D, ld = 3 * D;
+    const long row0 = (long)b * N;
+    const uint32_t QT = 0, KT = ATT_TILE_BYTES, VT = 2 * ATT_TILE_BYTES, DOT = 3 * ATT_TILE_BYTES;
+    const uint32_t LSE = 4 * ATT_TILE_BYTES, DEL = LSE + ATT_ROWS * 4;
+    const tic_rsrc_t rq = make_rsrc(p.qkv, (uint32_t)((size_t)p.B * N * ld * 2));
+    const tic_rsrc_t rdo = make_rsrc(p.d_o, (uint32_t)((size_t)p.B * N * D * 2));
+    att_stage_tile(rq, QT, row0, N, ld, h * ATT_HD, l, w);
+    att_stage_tile(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
+    att_stage_tile(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
+    att_stage_tile(rdo, DOT, row0, N, D, h * ATT_HD, l, w);
+    // delta[q] = sum_d dO[q,d] * O[q,d];  lse (log2 units); padded queries: lse = +inf -> P = 0
+    if (tid < ATT_ROWS) {
+        float dl = 0.f, ls = __builtin_huge_valf();
+        if (tid < N) {
+            const bf16_t* orow = p.o + (size_t)(row0 + tid) * D + h * ATT_HD;
+            const bf16_t* drow = p.d_o + (size_t)(row0 + tid) * D + h * ATT_HD;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + c8 * 8);
+                const bf16x8 dv = *reinterpret_cast<const bf16x8*>(drow + c8 * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)ov[j]) * bf2f((bf16_t)dv[j]);
+            }
+            ls = p.lse[(size_t)bh * N + tid] * 1.4426950408889634f;
+        }
+        lds_stf(LSE + 4u * tid, ls);
+        lds_stf(DEL + 4u * tid, dl);
+    }
+    wait_vmcnt0();
+    block_sync();
+
+    const int g = l >> 4, li = l & 15;
+    const float c = p.scale * 1.4426950408889634f;
+
+    // ---------------- phase A: dK, dV (key on the lane) ----------------
+    for (int kt = w; kt < 13; kt += 4) {
+        const int key = kt * 16 + li;
+        const bool key_ok = key < N;
+        bf16x8 fk[2], fv[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fk[ks] = lds_ld128(KT + att_row_off((uint32_t)key, (uint32_t)(ks * 4 + g)));
+            fv[ks] = lds_ld128(VT + att_row_off((uint32_t)key, (uint32_t)(ks * 4 + g)));
+        }
+        f32x4 dva[4], dka[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            dva[dt] = f32x4{0, 0, 0, 0};
+            dka[dt] = f32x4{0, 0, 0, 0};
+        }
+        for (int qp = 0; qp < 7; ++qp) {
+            f32x4 pv[2], dsv[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int qrow = (2 * qp + hh) * 16;
+                f32x4 sa = f32x4{0, 0, 0, 0}, da = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 fq = lds_ld128(QT + att_row_off((uint32_t)(qrow + li), (uint32_t)(ks * 4 + g)));
+                    const bf16x8 fd = lds_ld128(DOT + att_row_off((uint32_t)(qrow + li), (uint32_t)(ks * 4 + g)));
+                    sa = mfma16(fq, fk[ks], sa);   // S[q = qrow + 4g + r][key]
+                    da = mfma16(fd, fv[ks], da);   // dP[q][key]
+                }
+                const f32x4 ls4 = lds_ldf4(LSE + 4u * (uint32_t)(qrow + 4 * g));
+                const f32x4 dl4 = lds_ldf4(DEL + 4u * (uint32_t)(qrow + 4 * g));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = key_ok ? fast_exp2(sa[r] * c - ls4[r]) : 0.f;
+                    pv[hh][r] = pr;
+                    dsv[hh][r] = pr * (da[r] - dl4[r]) * p.scale;
+                }
+            }
+            const bf16x8 fp = pack8(pv[0], pv[1]), fds = pack8(dsv[0], dsv[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dva[dt] = mfma16(att_tr_frag(DOT, qp, dt, l), fp, dva[dt]);    // dV^T[d][key]
+                dka[dt] = mfma16(att_tr_frag(QT, qp, dt, l), fds, dka[dt]);    // dK^T[d][key]
+            }
+        }
+        if (key_ok) {
+            bf16_t* krow = p.dqkv + (size_t)(row0 + key) * ld + D + h * ATT_HD + 4 * g;
+            bf16_t* vrow = krow + D;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                *reinterpret_cast<u32x2*>(krow + dt * 16) = u32x2{pack2bf(dka[dt][0], dka[dt][1]), pack2bf(dka[dt][2], dka[dt][3])};
+                *reinterpret_cast<u32x2*>(vrow + dt * 16) = u32x2{pack2bf(dva[dt][0], dva[dt][1]), pack2bf(dva[dt][2], dva[dt][3])};
+            }
+        }
+    }
+
+    // ---------------- phase B: dQ (query on the lane) ----------------
+    for (int qb = w; qb < 13; qb += 4) {
+        const int q = qb * 16 + li;
+        bf16x8 fq[2], fd[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fq[ks] = lds_ld128(QT + att_row_off((uint32_t)q, (uint32_t)(ks * 4 + g)));
+            fd[ks] = lds_ld128(DOT + att_row_off((uint32_t)q, (uint32_t)(ks * 4 + g)));
+        }
+        const float ls = lds_ldf(LSE + 4u * (uint32_t)q), dl = lds_ldf(DEL + 4u * (uint32_t)q);
+        f32x4 dqa[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dqa[dt] = f32x4{0, 0, 0, 0};
+        for (int kp = 0; kp < 7; ++kp) {
+            f32x4 dsv[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int krow = (2 * kp + hh) * 16;
+                f32x4 sa = f32x4{0, 0, 0, 0}, da = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 fk = lds_ld128(KT + att_row_off((uint32_t)(krow + li), (uint32_t)(ks * 4 + g)));
+                    const bf16x8 fv = lds_ld128(VT + att_row_off((uint32_t)(krow + li), (uint32_t)(ks * 4 + g)));
+                    sa = mfma16(fk, fq[ks], sa);   // S^T[key = krow + 4g + r][q]
+                    da = mfma16(fv, fd[ks], da);   // dP^T[key][q]
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = (krow + 4 * g + r < N) ? fast_exp2(sa[r] * c - ls) : 0.f;
+                    dsv[hh][r] = pr * (da[r] - dl) * p.scale;
+                }
+            }
+            const bf16x8 fds = pack8(dsv[0], dsv[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dqa[dt] = mfma16(att_tr_frag(KT, kp, dt, l), fds, dqa[dt]);   // dQ^T[d][q]
+        }
+        if (q < N) {
+            bf16_t* qrow = p.dqkv + (size_t)(row0 + q) * ld + h * ATT_HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<u32x2*>(qrow + dt * 16) = u32x2{pack2bf(dqa[dt][0], dqa[dt][1]), pack2bf(dqa[dt][2], dqa[dt][3])};
+        }
+    }
+}

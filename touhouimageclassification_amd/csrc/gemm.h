@@ -1,0 +1,304 @@
+// gemm.h -- bf16 MFMA GEMMs for the ViT token stream (gfx950).
+//
+//   gemm_nt : C[M,N]  = A[M,K] . B[N,K]^T   (+ fused epilogue)     forward Linear and dX (with W^T copies)
+//   gemm_tn : C[N,K] += A[M,N]^T . B[M,K]                            dW = dY^T . X, fp32, split over M
+//
+// Replaces the cuBLAS calls behind nn.Linear in HF modeling_vit.py:202-205,216-218,235-236,
+// 246-247 (reached from TIC/ViT/model.py:27-45) and their autograd backward (TIC/ViT/finetune.py:62).
+//
+// Both: 128x128 block tile, 64-deep K step, 256 threads = 2x2 waves of 64x64, operands staged
+// HBM -> LDS by LDS-DMA (buffer_load ... lds, 16 B/lane) through a hardware-range-checked buffer
+// resource (ragged M needs no padding: rows past M read as 0), 2 LDS stages (64 KiB -> 2 blocks
+// per CU), XOR-swizzled 16-B chunks applied on the DMA *source* address and on the LDS read
+// (guide rule 21) so every fragment read is bank-conflict-free.
+#pragma once
+#include "tic_prims.h"
+
+// epilogue codes: TIC_EPI_* in include/tic_hip.h
+#include "../../include/tic_hip.h"
+
+struct GemmNtParams {
+    const bf16_t* A;   // [M,K]
+    const bf16_t* B;   // [N,K]
+    int M, N, K;
+    const float* bias;       // [N] or nullptr
+    bf16_t* out;             // [M,N] bf16
+    bf16_t* out2;            // [M,N] bf16 (GELU)
+    float* out_f32;          // [M,N] fp32 (RESID) / remapped rows (PATCH)
+    const float* resid;      // [M,N] fp32
+    const bf16_t* aux;       // [M,N] bf16 (DGELU: pre-activation u)
+    const float* rowtab;     // [(P+1),N] fp32 (PATCH: position embeddings)
+    int patches;             // P (PATCH)
+};
+
+// 16-byte-chunk XOR swizzle for 128-byte LDS rows: conflict-free for the 16x16x32 row-fragment
+// ds_read_b128 pattern AND for ds_read_b64_tr_b16 (see DESIGN.md "LDS images").
+TIC_DEV uint32_t swz128(uint32_t row) { return ((row >> 1) & 3u) << 1; }
+
+// XCD-aware, grouped tile order: blocks that share an XCD (bid % 8, guide T1) get a contiguous
+// range of tiles, walked GM m-tiles at a time so A and B panels are re-read from that XCD's L2.
+TIC_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsize = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_group = wg - group * per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
+}
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+#define GEMM_STAGE_BYTES 32768   // A tile 16 KiB + B tile 16 KiB
+#define GEMM_LDS_BYTES (2 * GEMM_STAGE_BYTES)
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
+    const int tid = TIC_TID, l = tid & 63, w = wave_id();
+    const int wm = w >> 1, wn = w & 1;
+    const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = p.N / GEMM_BN;
+    int tm, tn;
+    tile_coords(TIC_BID_X, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+    const tic_rsrc_t ra = make_rsrc(p.A, (uint32_t)((size_t)p.M * p.K * 2));
+    const tic_rsrc_t rb = make_rsrc(p.B, (uint32_t)((size_t)p.N * p.K * 2));
+
+    // ---- LDS-DMA source offsets (bytes) for this lane's 4 A chunks and 4 B chunks --------------
+    // chunk c = i*4 + w covers tile rows 8c..8c+7 (1 KiB); lane -> (row l>>3, physical 16-B slot l&7)
+    uint32_t voa[4], vob[4];
+    {
+        const uint32_t slot_log = (uint32_t)(l & 7) ^ ((((uint32_t)l >> 4) & 3u) << 1);   // = phys ^ swz128(row)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (i * 4 + w) * 8 + (l >> 3);
+            voa[i] = (uint32_t)(((size_t)(m0 + r) * p.K + slot_log * 8) * 2);
+            vob[i] = (uint32_t)(((size_t)(n0 + r) * p.K + slot_log * 8) * 2);
+        }
+    }
+    auto stage = [&](int buf, int kt) {
+        const uint32_t soff = (uint32_t)kt * (GEMM_BK * 2);
+        const uint32_t base = (uint32_t)buf * GEMM_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(ra, base + (uint32_t)(i * 4 + w) * 1024u, voa[i], soff);
+            glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, vob[i], soff);
+        }
+    };
+
+    // ---- fragment read offsets: row (l&15), logical chunk 4ks + (l>>4) -------------------------------
+    const uint32_t sw = (((uint32_t)(l & 15) >> 1) & 3u) << 1;
+    uint32_t fo[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fo[ks] = (uint32_t)(l & 15) * 128u + ((((uint32_t)ks * 4 + ((uint32_t)l >> 4)) ^ sw) * 16u);
+    const uint32_t a_base = (uint32_t)wm * 64 * 128, b_base = 16384u + (uint32_t)wn * 64 * 128;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / GEMM_BK;
+    stage(0, 0);
+    wait_vmcnt0();
+    block_sync();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const uint32_t sb = (uint32_t)cur * GEMM_STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = lds_ld128(sb + a_base + (uint32_t)t * 2048u + fo[ks]);
+                fb[t] = lds_ld128(sb + b_base + (uint32_t)t * 2048u + fo[ks]);
+            }
+            // swapped operands: D rows = n (4 consecutive per lane), D cols = m (lane&15)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
+        }
+        wait_vmcnt0();
+        block_sync();
+    }
+
+    // ---- epilogue: lane holds rows m = ..+(l&15), 4 consecutive n = ..+4(l>>4) ------------------------
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + (l & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + nt * 16 + 4 * (l >> 4);
+            f32x4 v = acc[mt][nt];
+            if (EPI != TIC_EPI_DGELU && p.bias) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+                v += b;
+            }
+            const size_t o = (size_t)m * p.N + n;
+            if (EPI == TIC_EPI_BF16) {
+                *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            } else if (EPI == TIC_EPI_GELU) {
+                float u[4], g[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    u[r] = bfround(v[r]);
+                    g[r] = gelu_erf(u[r]);
+                }
+                *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(u[0], u[1]), pack2bf(u[2], u[3])};
+                *reinterpret_cast<u32x2*>(p.out2 + o) = u32x2{pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
+            } else if (EPI == TIC_EPI_RESID) {
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + o);
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = rs[r] + bfround(v[r]);
+                *reinterpret_cast<f32x4*>(p.out_f32 + o) = y;
+            } else if (EPI == TIC_EPI_DGELU) {
+                const u32x2 ur = *reinterpret_cast<const u32x2*>(p.aux + o);
+                const float u0 = bf2f((bf16_t)(ur[0] & 0xffff)), u1 = bf2f((bf16_t)(ur[0] >> 16));
+                const float u2 = bf2f((bf16_t)(ur[1] & 0xffff)), u3 = bf2f((bf16_t)(ur[1] >> 16));
+                const float d0 = bfround(v[0]) * gelu_erf_grad(u0), d1 = bfround(v[1]) * gelu_erf_grad(u1);
+                const float d2 = bfround(v[2]) * gelu_erf_grad(u2), d3 = bfround(v[3]) * gelu_erf_grad(u3);
+                *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
+            } else if (EPI == TIC_EPI_PATCH) {
+                const int img = m / p.patches, pi = m - img * p.patches;
+                const size_t orow = (size_t)img * (p.patches + 1) + 1 + pi;
+                const f32x4 pe = *reinterpret_cast<const f32x4*>(p.rowtab + (size_t)(1 + pi) * p.N + n);
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = bfround(v[r]) + pe[r];
+                *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.N + n) = y;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// gemm_tn: C[N,K] (fp32, row-major, ldc = K) += sum_m A[m,n] * B[m,k]   -- dW = dY^T . X
+//   A = dY [M,N] bf16, B = X [M,K] bf16.  The reduction runs over M (ragged; rows past M read as 0
+//   through the buffer range check), split over gridDim.y slices that add their partial tile with
+//   fp32 atomics (one 32x32 accumulator register = two 128-B row segments per wave-instruction, the
+//   full-rate atomic shape of MI355X_MICROARCH "Global float atomics").  C must be zero (or hold the
+//   gradient being accumulated into) before the launch.
+//   Both operands are reduction-major in memory, so fragments come from ds_read_b64_tr_b16.
+//   LDS tiles: [64 m][128 n or k] bf16 = 256-B rows, 16 KiB each.
+struct GemmTnParams {
+    const bf16_t* A;   // [M,N]
+    const bf16_t* B;   // [M,K]
+    float* C;          // [N,K]
+    int M, N, K;
+    int m_per_slice;   // multiple of 64
+};
+
+// 16-B-chunk swizzle for 256-byte rows read by the 32x32x16 transposed-fragment pattern
+TIC_DEV uint32_t swz256(uint32_t row) { return (row & 3u) << 2; }
+
+__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
+    const int tid = TIC_TID, l = tid & 63, w = wave_id();
+    const int wn = w >> 1, wk = w & 1;
+    const int tiles_n = p.N / 128, tiles_k = p.K / 128;
+    int tnn, tkk;
+    tile_coords(TIC_BID_X, tiles_n * tiles_k, tiles_n, tiles_k, tnn, tkk);
+    const int n0 = tnn * 128, k0 = tkk * 128;
+    const int m_begin = TIC_BID_Y * p.m_per_slice;
+    int m_end = m_begin + p.m_per_slice;
+    if (m_end > p.M) m_end = p.M;
+    if (m_begin >= p.M) return;
+    const int nsteps = (m_end - m_begin + 63) / 64;
+
+    // range check at the END OF THIS SLICE so a partial last step reads zeros, not the next slice
+    const tic_rsrc_t ra = make_rsrc(p.A, (uint32_t)((size_t)m_end * p.N * 2));
+    const tic_rsrc_t rb = make_rsrc(p.B, (uint32_t)((size_t)m_end * p.K * 2));
+
+    // staging: a 1-KiB DMA piece = 4 rows x 256 B; piece c = i*4 + w covers tile rows 4c..4c+3;
+    // lane -> (row l>>4, physical chunk l&15); source chunk = phys ^ swz256(row)
+    uint32_t voa[4], vob[4];
+    {
+        const uint32_t rr = (uint32_t)l >> 4;                    // row within piece == row & 3
+        const uint32_t ch_log = ((uint32_t)l & 15u) ^ (rr << 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (i * 4 + w) * 4 + (int)rr;
+            voa[i] = (uint32_t)(((size_t)(m_begin + r) * p.N + n0 + ch_log * 8) * 2);
+            vob[i] = (uint32_t)(((size_t)(m_begin + r) * p.K + k0 + ch_log * 8) * 2);
+        }
+    }
+    // the row advance lives in the VGPR offset: only that offset is range-checked by the hardware
+    const uint32_t strideA = (uint32_t)p.N * 2 * 64, strideB = (uint32_t)p.K * 2 * 64;   // bytes per 64-row step
+    auto stage = [&](int buf) {
+        const uint32_t base = (uint32_t)buf * GEMM_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(ra, base + (uint32_t)(i * 4 + w) * 1024u, voa[i], 0);
+            glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, vob[i], 0);
+            voa[i] += strideA;
+            vob[i] += strideB;
+        }
+    };
+
+    // transposed-fragment addresses (32x32x16): lane l: h = l>>5, c16 = (l>>4)&1, q = (l>>2)&3, p4 = l&3
+    // supplies &tile[row = 16*ks + 8h + q (+4)][col = col0 + 16*c16 + 4*p4]
+    const uint32_t h = (uint32_t)l >> 5, c16 = ((uint32_t)l >> 4) & 1u, q = ((uint32_t)l >> 2) & 3u, p4 = (uint32_t)l & 3u;
+    auto tr_off = [&](uint32_t tile_base, uint32_t col0, uint32_t ks, uint32_t second) -> uint32_t {
+        const uint32_t row = 16 * ks + 8 * h + 4 * second + q;
+        const uint32_t col = col0 + 16 * c16 + 4 * p4;            // element column, multiple of 4
+        const uint32_t chunk = (col >> 3) ^ swz256(row);
+        return tile_base + row * 256u + chunk * 16u + (col & 4u) * 2u;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(0);
+    wait_vmcnt0();
+    block_sync();
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps) stage(cur ^ 1);
+        const uint32_t sb = (uint32_t)cur * GEMM_STAGE_BYTES;
+#pragma unroll
+        for (uint32_t ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (uint32_t t = 0; t < 2; ++t) {
+                const bf16x4 a0 = lds_tr64(tr_off(sb, (uint32_t)wn * 64 + t * 32, ks, 0));
+                const bf16x4 a1 = lds_tr64(tr_off(sb, (uint32_t)wn * 64 + t * 32, ks, 1));
+                const bf16x4 b0 = lds_tr64(tr_off(sb + 16384u, (uint32_t)wk * 64 + t * 32, ks, 0));
+                const bf16x4 b1 = lds_tr64(tr_off(sb + 16384u, (uint32_t)wk * 64 + t * 32, ks, 1));
+                fa[t] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                fb[t] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) acc[nt][kt] = mfma32(fa[nt], fb[kt], acc[nt][kt]);
+        }
+        wait_vmcnt0();
+        block_sync();
+    }
+
+    // D: col = l&31 -> k (contiguous in C), row = (r&3) + 8(r>>2) + 4(l>>5) -> n
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int kk = k0 + wk * 64 + kt * 32 + (l & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                atomic_addf(p.C + (size_t)n * p.K + kk, acc[nt][kt][r]);
+            }
+        }
+}

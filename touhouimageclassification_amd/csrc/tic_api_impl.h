@@ -1,0 +1,470 @@
+// tic_api_impl.h -- host side of the C ABI declared in include/tic_hip.h: argument checks, grid
+// selection, kernel launches, and the whole-model phase drivers.  Compiled into libtic_hip.so by
+// tic_hip.hip (device build) and, for CPU-side lane-map checks, into the test-only simulator
+// library by tests/sim/tic_sim.cpp; the TIC_RT_* macros are the only difference.
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/tic_hip.h"
+#include "attention.h"
+#include "elementwise.h"
+#include "gemm.h"
+#include "norm.h"
+
+static thread_local char g_tic_err[512] = "";
+static int tic_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_tic_err, sizeof(g_tic_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define TIC_REQUIRE(cond, ...) \
+    do {                       \
+        if (!(cond)) return tic_fail(TIC_EINVAL, __VA_ARGS__); \
+    } while (0)
+#define TIC_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)
+
+static int tic_after_launch(const char* what) {
+    const char* e = TIC_RT_LAST_ERROR();
+    if (e) return tic_fail(TIC_ELAUNCH, "%s: %s", what, e);
+    return TIC_OK;
+}
+
+extern "C" int tic_version(void) { return TIC_ABI_VERSION; }
+extern "C" const char* tic_last_error_string(void) { return g_tic_err; }
+
+// ---- GEMM ------------------------------------------------------------------------------------------
+extern "C" int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
+                                void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
+                                const void* aux_bf16, const float* rowtab, int patches, tic_stream_t stream) {
+    TIC_REQUIRE(A && B, "gemm_nt: null operand");
+    TIC_REQUIRE(M >= 1 && N >= 128 && K >= 64, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
+    TIC_REQUIRE(N % 128 == 0 && K % 64 == 0, "gemm_nt: need N %% 128 == 0 and K %% 64 == 0 (N=%d K=%d)", N, K);
+    TIC_REQUIRE(TIC_ALIGNED16(A) && TIC_ALIGNED16(B), "gemm_nt: operands must be 16-byte aligned");
+    const long tiles_m = (M + 127) / 128;
+    TIC_REQUIRE((double)tiles_m * 128.0 * K * 2.0 < 4294967296.0 && (double)N * K * 2.0 < 4294967296.0,
+                "gemm_nt: operand exceeds the 4 GiB buffer-resource range");
+    GemmNtParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.out = (bf16_t*)out_bf16; p.out2 = (bf16_t*)out2_bf16; p.out_f32 = out_f32; p.resid = resid;
+    p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches;
+    const int grid = (int)(tiles_m * (N / 128));
+    switch (epilogue) {
+        case TIC_EPI_BF16:
+            TIC_REQUIRE(out_bf16, "gemm_nt: EPI_BF16 needs out_bf16");
+            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_BF16>, GEMM_LDS_BYTES);
+            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_BF16>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            break;
+        case TIC_EPI_GELU:
+            TIC_REQUIRE(out_bf16 && out2_bf16, "gemm_nt: EPI_GELU needs out_bf16 and out2_bf16");
+            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_GELU>, GEMM_LDS_BYTES);
+            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_GELU>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            break;
+        case TIC_EPI_RESID:
+            TIC_REQUIRE(out_f32 && resid, "gemm_nt: EPI_RESID needs out_f32 and resid");
+            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_RESID>, GEMM_LDS_BYTES);
+            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_RESID>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            break;
+        case TIC_EPI_DGELU:
+            TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_DGELU needs out_bf16 and aux_bf16");
+            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_DGELU>, GEMM_LDS_BYTES);
+            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_DGELU>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            break;
+        case TIC_EPI_PATCH:
+            TIC_REQUIRE(out_f32 && rowtab && patches > 0 && M % patches == 0, "gemm_nt: EPI_PATCH needs out_f32, rowtab, M %% patches == 0");
+            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_PATCH>, GEMM_LDS_BYTES);
+            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_PATCH>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            break;
+        default:
+            return tic_fail(TIC_EINVAL, "gemm_nt: unknown epilogue %d", epilogue);
+    }
+    return tic_after_launch("gemm_nt");
+}
+
+extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, tic_stream_t stream) {
+    TIC_REQUIRE(A && B && C, "gemm_tn: null operand");
+    TIC_REQUIRE(M >= 1 && N % 128 == 0 && K % 128 == 0 && N >= 128 && K >= 128, "gemm_tn: need N, K multiples of 128 (M=%d N=%d K=%d)", M, N, K);
+    TIC_REQUIRE(TIC_ALIGNED16(A) && TIC_ALIGNED16(B), "gemm_tn: operands must be 16-byte aligned");
+    TIC_REQUIRE(((double)M + 64.0) * (N > K ? N : K) * 2.0 < 4294967296.0, "gemm_tn: operand exceeds the 4 GiB buffer-resource range");
+    const int tiles = (N / 128) * (K / 128);
+    // split the M reduction so that ~4 workgroups per CU are in flight (256 CUs)
+    int split = (1024 + tiles - 1) / tiles;
+    const int max_split = (M + 63) / 64;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    int m_per = ((M + split - 1) / split + 63) / 64 * 64;
+    split = (M + m_per - 1) / m_per;
+    GemmTnParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.m_per_slice = m_per;
+    TIC_RT_MAX_LDS(gemm_tn_kernel, GEMM_LDS_BYTES);
+    TIC_LAUNCH(gemm_tn_kernel, dim3(tiles, split), 256, GEMM_LDS_BYTES, stream, p);
+    return tic_after_launch("gemm_tn");
+}
+
+// ---- LayerNorm -------------------------------------------------------------------------------------
+static int ln_grid(int rows) {
+    int g = (rows + 3) / 4;
+    return g > 2048 ? 2048 : (g < 1 ? 1 : g);
+}
+extern "C" int tic_layernorm_fwd(const float* x, long in_stride, const float* gamma, const float* beta, void* y_bf16,
+                                 float* mean, float* rstd, int rows, int D, float eps, tic_stream_t stream) {
+    TIC_REQUIRE(x && gamma && beta && y_bf16 && mean && rstd, "layernorm_fwd: null pointer");
+    TIC_REQUIRE(rows >= 1 && D >= 4 && D % 4 == 0 && D <= 1024 && in_stride % 4 == 0, "layernorm_fwd: need D %% 4 == 0, D <= 1024 (D=%d)", D);
+    const int nv = (D + 255) / 256, grid = ln_grid(rows);
+#define TIC_LN_FWD(NV) TIC_LAUNCH(ln_fwd_kernel<NV>, grid, 256, 0, stream, x, in_stride, gamma, beta, (bf16_t*)y_bf16, mean, rstd, rows, D, eps)
+    if (nv == 1) TIC_LN_FWD(1); else if (nv == 2) TIC_LN_FWD(2); else if (nv == 3) TIC_LN_FWD(3); else TIC_LN_FWD(4);
+#undef TIC_LN_FWD
+    return tic_after_launch("layernorm_fwd");
+}
+extern "C" int tic_layernorm_bwd(const void* dy_bf16, const float* x, long stride, const float* gamma, const float* mean,
+                                 const float* rstd, const float* dres, float* dx, void* dxb_bf16, float* dgamma,
+                                 float* dbeta, int rows, int D, tic_stream_t stream) {
+    TIC_REQUIRE(dy_bf16 && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+    TIC_REQUIRE(rows >= 1 && D >= 4 && D % 4 == 0 && D <= 1024 && stride % 4 == 0, "layernorm_bwd: need D %% 4 == 0, D <= 1024 (D=%d)", D);
+    const int nv = (D + 255) / 256;
+    int grid = ln_grid(rows);
+    if (grid > 512) grid = 512;   // fewer, longer blocks: one dgamma/dbeta atomic row per block
+    const size_t lds = (size_t)2 * 4 * D * 4;
+#define TIC_LN_BWD(NV) TIC_LAUNCH(ln_bwd_kernel<NV>, grid, 256, lds, stream, (const bf16_t*)dy_bf16, x, stride, gamma, mean, rstd, dres, dx, (bf16_t*)dxb_bf16, dgamma, dbeta, rows, D)
+    if (nv == 1) TIC_LN_BWD(1); else if (nv == 2) TIC_LN_BWD(2); else if (nv == 3) TIC_LN_BWD(3); else TIC_LN_BWD(4);
+#undef TIC_LN_BWD
+    return tic_after_launch("layernorm_bwd");
+}
+
+// ---- attention -------------------------------------------------------------------------------------
+extern "C" int tic_attention_fwd(const void* qkv, void* o, float* lse, int B, int H, int N, float scale, tic_stream_t stream) {
+    TIC_REQUIRE(qkv && o && lse, "attention_fwd: null pointer");
+    TIC_REQUIRE(B >= 1 && H >= 1 && N >= 1 && N <= 208, "attention_fwd: need 1 <= N <= 208 (N=%d)", N);
+    TIC_REQUIRE((double)B * N * 3 * H * 64 * 2 < 4294967296.0, "attention_fwd: qkv exceeds the 4 GiB buffer-resource range");
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.qkv = (const bf16_t*)qkv; p.o = (bf16_t*)o; p.lse = lse; p.B = B; p.H = H; p.N = N; p.D = H * 64; p.scale = scale;
+    TIC_RT_MAX_LDS(attn_fwd_kernel, 2 * ATT_TILE_BYTES);
+    TIC_LAUNCH(attn_fwd_kernel, B * H, 256, 2 * ATT_TILE_BYTES, stream, p);
+    return tic_after_launch("attention_fwd");
+}
+extern "C" int tic_attention_bwd(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, int B,
+                                 int H, int N, float scale, tic_stream_t stream) {
+    TIC_REQUIRE(qkv && o && lse && d_o && dqkv, "attention_bwd: null pointer");
+    TIC_REQUIRE(B >= 1 && H >= 1 && N >= 1 && N <= 208, "attention_bwd: need 1 <= N <= 208 (N=%d)", N);
+    TIC_REQUIRE((double)B * N * 3 * H * 64 * 2 < 4294967296.0, "attention_bwd: qkv exceeds the 4 GiB buffer-resource range");
+    AttnParams p;
+    memset(&p, 0, sizeof(p));
+    p.qkv = (const bf16_t*)qkv; p.o = (bf16_t*)o; p.lse = (float*)lse; p.d_o = (const bf16_t*)d_o; p.dqkv = (bf16_t*)dqkv;
+    p.B = B; p.H = H; p.N = N; p.D = H * 64; p.scale = scale;
+    TIC_RT_MAX_LDS(attn_bwd_kernel, ATT_BWD_LDS);
+    TIC_LAUNCH(attn_bwd_kernel, B * H, 256, ATT_BWD_LDS, stream, p);
+    return tic_after_launch("attention_bwd");
+}
+
+// ---- element-wise ----------------------------------------------------------------------------------
+static int ew_grid(long work_items) {
+    long g = (work_items + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+extern "C" int tic_patchify(const float* x, void* P_bf16, int B, int C, int img, int patch, tic_stream_t stream) {
+    TIC_REQUIRE(x && P_bf16, "patchify: null pointer");
+    TIC_REQUIRE(B >= 1 && C >= 1 && patch % 8 == 0 && img % patch == 0, "patchify: need patch %% 8 == 0 and img %% patch == 0");
+    TIC_LAUNCH(patchify_kernel, ew_grid((long)B * C * img * (img / 8)), 256, 0, stream, x, (bf16_t*)P_bf16, B, C, img, patch);
+    return tic_after_launch("patchify");
+}
+extern "C" int tic_embed_cls(const float* cls, const float* pos, float* h, int B, int N, int D, tic_stream_t stream) {
+    TIC_REQUIRE(cls && pos && h && B >= 1, "embed_cls: bad argument");
+    TIC_LAUNCH(embed_cls_kernel, (B * D + 255) / 256, 256, 0, stream, cls, pos, h, B, N, D);
+    return tic_after_launch("embed_cls");
+}
+extern "C" int tic_embed_bwd(const float* dh, float* dcls, float* dpos, int B, int N, int D, tic_stream_t stream) {
+    TIC_REQUIRE(dh && dcls && dpos && B >= 1, "embed_bwd: bad argument");
+    TIC_LAUNCH(embed_bwd_kernel, (N * D + 255) / 256, 256, 0, stream, dh, dcls, dpos, B, N, D);
+    return tic_after_launch("embed_bwd");
+}
+__global__ void __launch_bounds__(256) gather_patch_rows_kernel(const float* __restrict__ dh, bf16_t* __restrict__ out, int B, int N, int D) {
+    const long total4 = (long)B * (N - 1) * D / 4;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total4; i += (long)TIC_NBLK_X * 256) {
+        const long e = i * 4, row = e / D;
+        const int d = (int)(e - row * D);
+        const long b = row / (N - 1), pi = row - b * (N - 1);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(dh + ((b * N + 1 + pi) * D + d));
+        *reinterpret_cast<u32x2*>(out + e) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    }
+}
+extern "C" int tic_gather_patch_rows(const float* dh, void* out_bf16, int B, int N, int D, tic_stream_t stream) {
+    TIC_REQUIRE(dh && out_bf16 && B >= 1 && N >= 2 && D % 4 == 0, "gather_patch_rows: bad argument");
+    TIC_LAUNCH(gather_patch_rows_kernel, ew_grid((long)B * (N - 1) * D / 4), 256, 0, stream, dh, (bf16_t*)out_bf16, B, N, D);
+    return tic_after_launch("gather_patch_rows");
+}
+extern "C" int tic_colsum_bf16(const void* in_bf16, float* out, int M, int N, tic_stream_t stream) {
+    TIC_REQUIRE(in_bf16 && out && M >= 1 && N >= 8 && N % 8 == 0, "colsum: need N %% 8 == 0");
+    int rs = (M + 63) / 64;
+    if (rs > 64) rs = 64;
+    TIC_LAUNCH(colsum_kernel, dim3((N + 255) / 256, rs), 256, 8 * 256 * 4, stream, (const bf16_t*)in_bf16, out, M, N);
+    return tic_after_launch("colsum");
+}
+extern "C" int tic_cast_bf16(const float* in, void* out_bf16, long n, tic_stream_t stream) {
+    TIC_REQUIRE(in && out_bf16 && n >= 4 && n % 4 == 0, "cast_bf16: need n %% 4 == 0");
+    TIC_LAUNCH(cast_bf16_kernel, ew_grid(n / 4), 256, 0, stream, in, (bf16_t*)out_bf16, n / 4);
+    return tic_after_launch("cast_bf16");
+}
+extern "C" int tic_cast_transpose_bf16(const float* in, void* out_bf16, int R, int C, tic_stream_t stream) {
+    TIC_REQUIRE(in && out_bf16 && R % 64 == 0 && C % 64 == 0 && R >= 64 && C >= 64, "cast_transpose: need R, C multiples of 64");
+    TIC_LAUNCH(cast_transpose_kernel, dim3(C / 64, R / 64), 256, 64 * CT_STRIDE * 2, stream, in, (bf16_t*)out_bf16, R, C);
+    return tic_after_launch("cast_transpose");
+}
+extern "C" int tic_adamw(float* p, const float* g, float* m, float* v, void* w16, long n, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int step, tic_stream_t stream) {
+    TIC_REQUIRE(p && g && m && v && n >= 4 && n % 4 == 0 && step >= 1, "adamw: need n %% 4 == 0 and step >= 1");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    TIC_LAUNCH(adamw_kernel, ew_grid(n / 4), 256, 0, stream, p, g, m, v, (bf16_t*)w16, n / 4, lr, beta1, beta2, eps,
+               weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    return tic_after_launch("adamw");
+}
+extern "C" int tic_head_fwd(const void* z_bf16, const float* W, const float* bias, float* logits, int B, int C, int D,
+                            tic_stream_t stream) {
+    TIC_REQUIRE(z_bf16 && W && bias && logits && B >= 1 && C >= 1 && D % 4 == 0, "head_fwd: bad argument");
+    TIC_LAUNCH(head_fwd_kernel, (B * C + 3) / 4, 256, 0, stream, (const bf16_t*)z_bf16, W, bias, logits, B, C, D);
+    return tic_after_launch("head_fwd");
+}
+extern "C" int tic_head_bwd(const float* dlogits, const void* z_bf16, const float* W, void* dz_bf16, float* dW, float* db,
+                            int B, int C, int D, tic_stream_t stream) {
+    TIC_REQUIRE(dlogits && z_bf16 && W && dz_bf16 && dW && db && B >= 1 && C >= 1, "head_bwd: bad argument");
+    TIC_LAUNCH(head_bwd_dz_kernel, (B * D + 255) / 256, 256, 0, stream, dlogits, W, (bf16_t*)dz_bf16, B, C, D);
+    TIC_LAUNCH(head_bwd_dw_kernel, (C * D + 255) / 256, 256, 0, stream, dlogits, (const bf16_t*)z_bf16, dW, db, B, C, D);
+    return tic_after_launch("head_bwd");
+}
+extern "C" int tic_softmax_xent(const float* logits, const int64_t* labels, const float* soft, float* loss_sum,
+                                float* dlogits, int B, int C, float gscale, tic_stream_t stream) {
+    TIC_REQUIRE(logits && loss_sum && B >= 1 && C >= 1, "softmax_xent: bad argument");
+    TIC_REQUIRE((labels != nullptr) != (soft != nullptr), "softmax_xent: exactly one of labels / soft must be given");
+    TIC_LAUNCH(xent_kernel, (B + 3) / 4, 256, 0, stream, logits, (const long long*)labels, soft, loss_sum, dlogits, B, C, gscale);
+    return tic_after_launch("softmax_xent");
+}
+
+// ---- whole-model layout + phase drivers -------------------------------------------------------------
+static long pad8(long n) { return (n + 7) / 8 * 8; }
+static size_t pad256(size_t n) { return (n + 255) / 256 * 256; }
+
+extern "C" int tic_vit_layout(const TicVitDims* d, TicVitLayout* o) {
+    TIC_REQUIRE(d && o, "vit_layout: null pointer");
+    TIC_REQUIRE(d->B >= 1 && d->L >= 1 && d->C >= 1 && d->H >= 1 && d->D == d->H * 64, "vit_layout: need D == H * 64 (D=%d H=%d)", d->D, d->H);
+    TIC_REQUIRE(d->D % 128 == 0 && d->F % 128 == 0 && d->D <= 1024, "vit_layout: need D, F multiples of 128 and D <= 1024");
+    TIC_REQUIRE(d->patch % 8 == 0 && d->img % d->patch == 0 && (d->chans * d->patch * d->patch) % 128 == 0, "vit_layout: bad image geometry");
+    const long D = d->D, F = d->F, C = d->C, L = d->L, G = d->img / d->patch, N = G * G + 1, PK = (long)d->chans * d->patch * d->patch;
+    TIC_REQUIRE(N <= 208, "vit_layout: tokens per image must be <= 208 (got %ld)", N);
+    memset(o, 0, sizeof(*o));
+    long off = 0;
+    o->cls = off; off += pad8(D);
+    o->pos = off; off += pad8(N * D);
+    o->patch_w = off; off += pad8(D * PK);
+    o->patch_b = off; off += pad8(D);
+    o->layer0 = off;
+    long lo = 0;
+    o->ln1_g = lo; lo += pad8(D);
+    o->ln1_b = lo; lo += pad8(D);
+    o->wqkv = lo; lo += pad8(3 * D * D);
+    o->bqkv = lo; lo += pad8(3 * D);
+    o->wo = lo; lo += pad8(D * D);
+    o->bo = lo; lo += pad8(D);
+    o->ln2_g = lo; lo += pad8(D);
+    o->ln2_b = lo; lo += pad8(D);
+    o->w1 = lo; lo += pad8(F * D);
+    o->b1 = lo; lo += pad8(F);
+    o->w2 = lo; lo += pad8(D * F);
+    o->b2 = lo; lo += pad8(D);
+    o->layer_stride = lo;
+    off += L * lo;
+    o->lnf_g = off; off += pad8(D);
+    o->lnf_b = off; off += pad8(D);
+    o->cls_w = off; off += pad8(C * D);
+    o->cls_b = off; off += pad8(C);
+    o->n_params = off;
+    long to = 0;
+    o->t_wqkv = to; to += 3 * D * D;
+    o->t_wo = to; to += D * D;
+    o->t_w1 = to; to += F * D;
+    o->t_w2 = to; to += D * F;
+    o->t_layer_stride = to;
+    o->t_total = L * to;
+    // activations
+    const size_t B = d->B, M = B * N;
+    size_t w = 0;
+    o->P = w; w += pad256(B * (N - 1) * PK * 2);
+    o->hs = w; o->hs_stride = pad256(M * D * 4); w += (L + 1) * o->hs_stride;
+    size_t lw = 0;
+    o->a1 = lw; lw += pad256(M * D * 2);
+    o->mean1 = lw; lw += pad256(M * 4);
+    o->rstd1 = lw; lw += pad256(M * 4);
+    o->qkv = lw; lw += pad256(M * 3 * D * 2);
+    o->lse = lw; lw += pad256(B * d->H * N * 4);
+    o->o = lw; lw += pad256(M * D * 2);
+    o->hmid = lw; lw += pad256(M * D * 4);
+    o->a2 = lw; lw += pad256(M * D * 2);
+    o->mean2 = lw; lw += pad256(M * 4);
+    o->rstd2 = lw; lw += pad256(M * 4);
+    o->u = lw; lw += pad256(M * F * 2);
+    o->g = lw; lw += pad256(M * F * 2);
+    o->layer_ws = w; o->layer_ws_stride = lw; w += L * lw;
+    o->zf = w; w += pad256(B * D * 2);
+    o->meanf = w; w += pad256(B * 4);
+    o->rstdf = w; w += pad256(B * 4);
+    o->logits = w; w += pad256(B * C * 4);
+    o->dlogits = w; w += pad256(B * C * 4);
+    o->dzf = w; w += pad256(B * D * 2);
+    o->dh = w; w += pad256(M * D * 4);
+    o->dhb = w; w += pad256(M * D * 2);
+    o->du = w; w += pad256(M * F * 2);
+    o->da = w; w += pad256(M * D * 2);
+    o->dqkv = w; w += pad256(M * 3 * D * 2);
+    o->dpatch = w; w += pad256(B * (N - 1) * D * 2);
+    o->ws_bytes = w;
+    return TIC_OK;
+}
+
+#define TIC_TRY(call)            \
+    do {                         \
+        const int rc_ = (call);  \
+        if (rc_ != TIC_OK) return rc_; \
+    } while (0)
+
+struct VitCtx {
+    TicVitLayout lay;
+    long D, F, C, L, N, M, PK, B, H;
+    float* P;       // params
+    float* G;       // grads
+    bf16_t* W16;
+    bf16_t* WT;
+    char* ws;
+    float eps;
+};
+static int vit_ctx(const TicVitState* st, VitCtx& c) {
+    TIC_REQUIRE(st && st->params && st->grads && st->w16 && st->wT16 && st->workspace, "vit: null state pointer");
+    TIC_TRY(tic_vit_layout(&st->dims, &c.lay));
+    const TicVitDims& d = st->dims;
+    const long G = d.img / d.patch;
+    c.D = d.D; c.F = d.F; c.C = d.C; c.L = d.L; c.N = G * G + 1; c.B = d.B; c.M = c.B * c.N; c.H = d.H;
+    c.PK = (long)d.chans * d.patch * d.patch;
+    c.P = st->params; c.G = st->grads; c.W16 = (bf16_t*)st->w16; c.WT = (bf16_t*)st->wT16; c.ws = (char*)st->workspace;
+    c.eps = d.eps;
+    return TIC_OK;
+}
+
+extern "C" int tic_vit_refresh_weights(const TicVitState* st, tic_stream_t s) {
+    VitCtx c;
+    TIC_TRY(vit_ctx(st, c));
+    const TicVitLayout& y = c.lay;
+    TIC_TRY(tic_cast_bf16(c.P, c.W16, y.n_params, s));
+    for (long l = 0; l < c.L; ++l) {
+        const float* lp = c.P + y.layer0 + l * y.layer_stride;
+        bf16_t* lt = c.WT + l * y.t_layer_stride;
+        TIC_TRY(tic_cast_transpose_bf16(lp + y.wqkv, lt + y.t_wqkv, (int)(3 * c.D), (int)c.D, s));
+        TIC_TRY(tic_cast_transpose_bf16(lp + y.wo, lt + y.t_wo, (int)c.D, (int)c.D, s));
+        TIC_TRY(tic_cast_transpose_bf16(lp + y.w1, lt + y.t_w1, (int)c.F, (int)c.D, s));
+        TIC_TRY(tic_cast_transpose_bf16(lp + y.w2, lt + y.t_w2, (int)c.D, (int)c.F, s));
+    }
+    return TIC_OK;
+}
+
+extern "C" int tic_vit_forward(const TicVitState* st, const float* x, float* logits_out, tic_stream_t s) {
+    VitCtx c;
+    TIC_TRY(vit_ctx(st, c));
+    TIC_REQUIRE(x, "vit_forward: null pixel_values");
+    const TicVitLayout& y = c.lay;
+    const int M = (int)c.M, D = (int)c.D, F = (int)c.F, B = (int)c.B, N = (int)c.N;
+    bf16_t* Pm = (bf16_t*)(c.ws + y.P);
+    float* h0 = (float*)(c.ws + y.hs);
+    TIC_TRY(tic_patchify(x, Pm, B, st->dims.chans, st->dims.img, st->dims.patch, s));
+    TIC_TRY(tic_gemm_nt_bf16(Pm, c.W16 + y.patch_w, B * (N - 1), D, (int)c.PK, TIC_EPI_PATCH, c.P + y.patch_b, nullptr, nullptr, h0,
+                             nullptr, nullptr, c.P + y.pos, N - 1, s));
+    TIC_TRY(tic_embed_cls(c.P + y.cls, c.P + y.pos, h0, B, N, D, s));
+    for (long l = 0; l < c.L; ++l) {
+        const float* lp = c.P + y.layer0 + l * y.layer_stride;
+        const bf16_t* lw = c.W16 + y.layer0 + l * y.layer_stride;
+        char* a = c.ws + y.layer_ws + l * y.layer_ws_stride;
+        float* hin = (float*)(c.ws + y.hs + l * y.hs_stride);
+        float* hout = (float*)(c.ws + y.hs + (l + 1) * y.hs_stride);
+        float* hmid = (float*)(a + y.hmid);
+        TIC_TRY(tic_layernorm_fwd(hin, D, lp + y.ln1_g, lp + y.ln1_b, a + y.a1, (float*)(a + y.mean1), (float*)(a + y.rstd1), M, D, c.eps, s));
+        TIC_TRY(tic_gemm_nt_bf16(a + y.a1, lw + y.wqkv, M, 3 * D, D, TIC_EPI_BF16, lp + y.bqkv, a + y.qkv, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
+        TIC_TRY(tic_attention_fwd(a + y.qkv, a + y.o, (float*)(a + y.lse), B, (int)c.H, N, 0.125f, s));
+        TIC_TRY(tic_gemm_nt_bf16(a + y.o, lw + y.wo, M, D, D, TIC_EPI_RESID, lp + y.bo, nullptr, nullptr, hmid, hin, nullptr, nullptr, 0, s));
+        TIC_TRY(tic_layernorm_fwd(hmid, D, lp + y.ln2_g, lp + y.ln2_b, a + y.a2, (float*)(a + y.mean2), (float*)(a + y.rstd2), M, D, c.eps, s));
+        TIC_TRY(tic_gemm_nt_bf16(a + y.a2, lw + y.w1, M, F, D, TIC_EPI_GELU, lp + y.b1, a + y.u, a + y.g, nullptr, nullptr, nullptr, nullptr, 0, s));
+        TIC_TRY(tic_gemm_nt_bf16(a + y.g, lw + y.w2, M, D, F, TIC_EPI_RESID, lp + y.b2, nullptr, nullptr, hout, hmid, nullptr, nullptr, 0, s));
+    }
+    float* hL = (float*)(c.ws + y.hs + c.L * y.hs_stride);
+    TIC_TRY(tic_layernorm_fwd(hL, (long)N * D, c.P + y.lnf_g, c.P + y.lnf_b, c.ws + y.zf, (float*)(c.ws + y.meanf), (float*)(c.ws + y.rstdf), B, D, c.eps, s));
+    float* lg = (float*)(c.ws + y.logits);
+    TIC_TRY(tic_head_fwd(c.ws + y.zf, c.P + y.cls_w, c.P + y.cls_b, lg, B, (int)c.C, D, s));
+    if (logits_out && logits_out != lg) TIC_RT_MEMCPY(logits_out, lg, (size_t)B * c.C * 4, s);
+    return TIC_OK;
+}
+
+extern "C" int tic_vit_backward_head(const TicVitState* st, const float* dlogits, tic_stream_t s) {
+    VitCtx c;
+    TIC_TRY(vit_ctx(st, c));
+    TIC_REQUIRE(dlogits, "vit_backward_head: null dlogits");
+    const TicVitLayout& y = c.lay;
+    const int D = (int)c.D, B = (int)c.B, N = (int)c.N;
+    float* dh = (float*)(c.ws + y.dh);
+    TIC_TRY(tic_head_bwd(dlogits, c.ws + y.zf, c.P + y.cls_w, c.ws + y.dzf, c.G + y.cls_w, c.G + y.cls_b, B, (int)c.C, D, s));
+    TIC_RT_MEMSET(dh, 0, (size_t)c.M * D * 4, s);
+    TIC_RT_MEMSET(c.ws + y.dhb, 0, (size_t)c.M * D * 2, s);
+    float* hL = (float*)(c.ws + y.hs + c.L * y.hs_stride);
+    TIC_TRY(tic_layernorm_bwd(c.ws + y.dzf, hL, (long)N * D, c.P + y.lnf_g, (float*)(c.ws + y.meanf), (float*)(c.ws + y.rstdf), nullptr, dh,
+                              c.ws + y.dhb, c.G + y.lnf_g, c.G + y.lnf_b, B, D, s));
+    return TIC_OK;
+}
+
+extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stream_t s) {
+    VitCtx c;
+    TIC_TRY(vit_ctx(st, c));
+    TIC_REQUIRE(layer >= 0 && layer < c.L, "vit_backward_layer: layer %d out of range", layer);
+    const TicVitLayout& y = c.lay;
+    const int M = (int)c.M, D = (int)c.D, F = (int)c.F, B = (int)c.B, N = (int)c.N;
+    const long l = layer;
+    const float* lp = c.P + y.layer0 + l * y.layer_stride;
+    float* lg = c.G + y.layer0 + l * y.layer_stride;
+    const bf16_t* lt = c.WT + l * y.t_layer_stride;
+    char* a = c.ws + y.layer_ws + l * y.layer_ws_stride;
+    float* hin = (float*)(c.ws + y.hs + l * y.hs_stride);
+    float* dh = (float*)(c.ws + y.dh);
+    char* dhb = c.ws + y.dhb;
+    char* du = c.ws + y.du;
+    char* da = c.ws + y.da;
+    char* dqkv = c.ws + y.dqkv;
+    // MLP
+    TIC_TRY(tic_gemm_nt_bf16(dhb, lt + y.t_w2, M, F, D, TIC_EPI_DGELU, nullptr, du, nullptr, nullptr, nullptr, a + y.u, nullptr, 0, s));
+    TIC_TRY(tic_gemm_tn_bf16(dhb, a + y.g, lg + y.w2, M, D, F, s));
+    TIC_TRY(tic_colsum_bf16(dhb, lg + y.b2, M, D, s));
+    TIC_TRY(tic_gemm_nt_bf16(du, lt + y.t_w1, M, D, F, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
+    TIC_TRY(tic_gemm_tn_bf16(du, a + y.a2, lg + y.w1, M, F, D, s));
+    TIC_TRY(tic_colsum_bf16(du, lg + y.b1, M, F, s));
+    TIC_TRY(tic_layernorm_bwd(da, (float*)(a + y.hmid), D, lp + y.ln2_g, (float*)(a + y.mean2), (float*)(a + y.rstd2), dh, dh, dhb, lg + y.ln2_g,
+                              lg + y.ln2_b, M, D, s));
+    // attention
+    TIC_TRY(tic_gemm_nt_bf16(dhb, lt + y.t_wo, M, D, D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
+    TIC_TRY(tic_gemm_tn_bf16(dhb, a + y.o, lg + y.wo, M, D, D, s));
+    TIC_TRY(tic_colsum_bf16(dhb, lg + y.bo, M, D, s));
+    TIC_TRY(tic_attention_bwd(a + y.qkv, a + y.o, (float*)(a + y.lse), da, dqkv, B, (int)c.H, N, 0.125f, s));
+    TIC_TRY(tic_gemm_nt_bf16(dqkv, lt + y.t_wqkv, M, D, 3 * D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
+    TIC_TRY(tic_gemm_tn_bf16(dqkv, a + y.a1, lg + y.wqkv, M, 3 * D, D, s));
+    TIC_TRY(tic_colsum_bf16(dqkv, lg + y.bqkv, M, 3 * D, s));
+    TIC_TRY(tic_layernorm_bwd(da, hin, D, lp + y.ln1_g, (float*)(a + y.mean1), (float*)(a + y.rstd1), dh, dh, dhb, lg + y.ln1_g, lg + y.ln1_b, M, D, s));
+    return TIC_OK;
+}
+
+extern "C" int tic_vit_backward_embed(const TicVitState* st, tic_stream_t s) {
+    VitCtx c;
+    TIC_TRY(vit_ctx(st, c));
+    const TicVitLayout& y = c.lay;
+    const int D = (int)c.D, B = (int)c.B, N = (int)c.N;
+    float* dh = (float*)(c.ws + y.dh);
+    TIC_TRY(tic_embed_bwd(dh, c.G + y.cls, c.G + y.pos, B, N, D, s));
+    TIC_TRY(tic_gather_patch_rows(dh, c.ws + y.dpatch, B, N, D, s));
+    TIC_TRY(tic_gemm_tn_bf16(c.ws + y.dpatch, c.ws + y.P, c.G + y.patch_w, B * (N - 1), D, (int)c.PK, s));
+    TIC_TRY(tic_colsum_bf16(c.ws + y.dpatch, c.G + y.patch_b, B * (N - 1), D, s));
+    return TIC_OK;
+}

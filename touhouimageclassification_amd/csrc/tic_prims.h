@@ -1,0 +1,143 @@
+// tic_prims.h -- the only place gfx950 builtins are spelled.
+//
+// Device build (hipcc --offload-arch=gfx950): thin always-inline wrappers over the CDNA4
+// builtins (MFMA, LDS-DMA buffer loads, ds_read_b64_tr_b16, raw barriers, counted waits).
+// Simulator build (-DTIC_SIM, clang++ -x c++, tests/sim/): the same names are provided by
+// tests/sim/sim_runtime.h, which executes a workgroup as 64-lane lock-step fibers on the
+// CPU so that lane maps / LDS swizzles / bounds handling can be checked without a GPU.
+// The simulator is TEST INFRASTRUCTURE: the shipped library contains only the device build.
+#pragma once
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment (4 VGPR)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;   // 4 bf16 (2 VGPR)
+typedef __attribute__((ext_vector_type(2))) short bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef unsigned short bf16_t;   // storage type of a bf16 element in memory
+
+#ifdef TIC_SIM
+#include "sim_runtime.h"
+#else
+#include <hip/hip_runtime.h>
+
+#define TIC_DEV __device__ __forceinline__
+#define TIC_KERNEL(name) extern "C" __global__ void name
+
+// ---- dynamic LDS -----------------------------------------------------------------------------
+// One dynamic array, 16-byte aligned, no static __shared__ beside it (guide G17 / "second
+// __shared__ object" trap).  All LDS addressing is by BYTE OFFSET into this array.
+extern __shared__ __attribute__((aligned(16))) char tic_smem[];
+
+TIC_DEV bf16x8 lds_ld128(uint32_t off) { return *reinterpret_cast<const bf16x8*>(tic_smem + off); }
+TIC_DEV bf16x4 lds_ld64(uint32_t off) { return *reinterpret_cast<const bf16x4*>(tic_smem + off); }
+TIC_DEV float lds_ldf(uint32_t off) { return *reinterpret_cast<const float*>(tic_smem + off); }
+TIC_DEV f32x4 lds_ldf4(uint32_t off) { return *reinterpret_cast<const f32x4*>(tic_smem + off); }
+TIC_DEV void lds_st128(uint32_t off, bf16x8 v) { *reinterpret_cast<bf16x8*>(tic_smem + off) = v; }
+TIC_DEV void lds_st64(uint32_t off, bf16x4 v) { *reinterpret_cast<bf16x4*>(tic_smem + off) = v; }
+TIC_DEV void lds_stf(uint32_t off, float v) { *reinterpret_cast<float*>(tic_smem + off) = v; }
+TIC_DEV void lds_stf4(uint32_t off, f32x4 v) { *reinterpret_cast<f32x4*>(tic_smem + off) = v; }
+TIC_DEV void lds_addf(uint32_t off, float v) { atomicAdd(reinterpret_cast<float*>(tic_smem + off), v); }
+
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of block row q,
+// columns 4p..4p+3 (8 bytes); lane i receives column i of the 4 rows (guide T10).
+// EXEC must be all ones.
+TIC_DEV bf16x4 lds_tr64(uint32_t off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(
+            (__attribute__((address_space(3))) char*)tic_smem + off));
+}
+
+// ---- buffer resources + LDS-DMA -----------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t tic_rsrc_t;
+// bytes: hardware range check -- loads past it return 0, stores past it are dropped.
+TIC_DEV tic_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+// 16 B per lane, global[voff + soff] -> LDS[lds_off + lane*16]; lds_off must be wave-uniform.
+TIC_DEV void glds16(tic_rsrc_t r, uint32_t lds_off, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        r, (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) char*)tic_smem + lds_off),
+        16, voff, soff, 0, 0);
+}
+TIC_DEV u32x4 buf_ld128(tic_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+TIC_DEV u32x2 buf_ld64(tic_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+}
+TIC_DEV void buf_st128(tic_rsrc_t r, u32x4 v, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+TIC_DEV void buf_st64(tic_rsrc_t r, u32x2 v, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
+// ---- waits / barriers ---------------------------------------------------------------------------
+TIC_DEV void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <int N> TIC_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+TIC_DEV void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+TIC_DEV void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+TIC_DEV void block_sync() { __syncthreads(); }
+TIC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+TIC_DEV void prio_hi() { __builtin_amdgcn_s_setprio(1); }
+TIC_DEV void prio_lo() { __builtin_amdgcn_s_setprio(0); }
+
+// ---- MFMA ---------------------------------------------------------------------------------------
+// 16x16x32 bf16: lane l holds A[row l&15][k 8(l>>4)+j], B[k 8(l>>4)+j][col l&15];
+//                D: col = l&15, row = 4(l>>4)+reg.
+TIC_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// 32x32x16 bf16: lane l holds A[row l&31][k 8(l>>5)+j], B[k 8(l>>5)+j][col l&31];
+//                D: col = l&31, row = (reg&3) + 8(reg>>2) + 4(l>>5).
+TIC_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---- cross-lane ---------------------------------------------------------------------------------
+TIC_DEV float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+TIC_DEV int lane_id() { return threadIdx.x & 63; }
+TIC_DEV int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+TIC_DEV uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+TIC_DEV void atomic_addf(float* p, float v) { atomicAdd(p, v); }
+TIC_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; exp2(-inf) = 0
+TIC_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+
+#define TIC_TID ((int)threadIdx.x)
+#define TIC_BID_X ((int)blockIdx.x)
+#define TIC_BID_Y ((int)blockIdx.y)
+#define TIC_BID_Z ((int)blockIdx.z)
+#define TIC_NBLK_X ((int)gridDim.x)
+#define TIC_NBLK_Y ((int)gridDim.y)
+#define TIC_NTHR ((int)blockDim.x)
+
+#define TIC_LAUNCH(kern, grid, block, lds, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)(stream), __VA_ARGS__)
+#endif  // !TIC_SIM
+
+// ---- numerics shared by both builds -------------------------------------------------------------
+TIC_DEV float bf2f(bf16_t u) {
+    union { uint32_t i; float f; } x;
+    x.i = ((uint32_t)u) << 16;
+    return x.f;
+}
+// round-to-nearest-even via the compiler's cast (v_cvt_pk_bf16_f32 on gfx950: NaN stays NaN)
+TIC_DEV bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+TIC_DEV float bfround(float f) { return bf2f(f2bf(f)); }
+TIC_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// exact-erf GELU (HF activations.py:83) and its derivative
+TIC_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+TIC_DEV float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
