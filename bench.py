@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the ViT-L/16 224 px bf16 fine-tune step (fwd + CE + bwd + gradient
+all-reduce + AdamW) on synthetic 3x224x224 batches, weak scaling over N MI355X (one process per GPU).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `roofline`: whole-step algorithmic FLOPs (369.32 GFLOP per
+image for ViT-L/16 C=120, train = 3 x fwd) / measured time vs the dense bf16 MFMA peak (2.5 PFLOP/s),
+plus the dominant kernel (gemm_nt, fc1 shape) timed on its own with HIP events on its launch stream.
+`cpu_baseline`: the CPU oracle (oracle/vit_oracle.py, a port) timed on this box's host cores, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODELS = {
+    "large": dict(name="google/vit-large-patch16-224", hidden=1024, layers=24, heads=16, mlp=4096),
+    "base": dict(name="google/vit-base-patch16-224", hidden=768, layers=12, heads=12, mlp=3072),
+}
+PEAK_BF16_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md chip table
+
+
+def train_flops_per_image(m, C):
+    N, D, L = 197, m["hidden"], m["layers"]
+    fwd = L * (24 * N * D * D + 4 * N * N * D) + 2 * 196 * 768 * D + 2 * D * C
+    return 3.0 * fwd
+
+
+def cpu_baseline(model_key, C, seconds_budget=25.0):
+    """oracle fwd+bwd+AdamW (fp32, B=4) on the host cores: a reported baseline, not a target"""
+    from oracle import vit_oracle as vo
+    m = MODELS[model_key]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = vo.ViTSpec(hidden=m["hidden"], layers=m["layers"], heads=m["heads"], mlp=m["mlp"], num_labels=C)
+    params = vo.init_params(spec, seed=0)
+    B = 4
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, C, (B,), generator=g)
+    mom = {k: torch.zeros_like(v) for k, v in params.items()}
+    var = {k: torch.zeros_like(v) for k, v in params.items()}
+
+    def step(i):
+        _, _, grads = vo.loss_and_grads(params, x, y, spec)
+        for k in params:
+            vo.adamw_step(params[k], grads[k], mom[k], var[k], i, lr=1e-5, wd=0.01)
+
+    step(1)   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
+        n += 1
+        step(n + 1)
+    dt = time.perf_counter() - t0
+    return dict(value=round(B * n / dt, 3), unit="images/sec", cores=cores, kind="port",
+                sample=f"{n} steps of fwd+bwd+AdamW, ViT-{model_key} C={C} B={B} fp32, torch CPU ops via oracle/vit_oracle.py")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (weak scaling)")
+    ap.add_argument("--model", default="large", choices=list(MODELS))
+    ap.add_argument("--classes", type=int, default=120)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--autograd", action="store_true", help="drive the step through torch autograd + F.cross_entropy (plugin surface) instead of the fused step")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the TIC hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from touhouimageclassification_amd.ViT.model import ViT
+    from touhouimageclassification_amd.dist import BucketedGradSync
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from touhouimageclassification_amd.step import fused_train_step
+    from touhouimageclassification_amd import ops
+
+    m = MODELS[args.model]
+    C, B = args.classes, args.batch
+    torch.manual_seed(0)
+    model = ViT(C, pretrained=False, model_name=m["name"])
+    model.reset_parameters(seed=0)
+    model.to(dev)
+    sync = BucketedGradSync(model)
+    sync.broadcast_parameters()
+    opt = FusedAdamW(model, lr=1e-5, weight_decay=0.01)   # ntrain.py:256-257
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    y = torch.randint(0, C, (B,), generator=g).to(dev)
+
+    def step():
+        if args.autograd:
+            opt.zero_grad()
+            loss = torch.nn.functional.cross_entropy(model(x).logits, y) * sync.grad_scale
+            loss.backward()
+            sync.wait()
+            opt.step()
+            return loss
+        return fused_train_step(model, opt, x, y, sync)[0]
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = tt.item()
+    loss_v = float(loss)
+
+    # dominant kernel on its own: gemm_nt at the fc1 shape [M,D] x [F,D]^T with the GELU epilogue,
+    # HIP events on the stream it is launched on (torch's current stream)
+    dom = None
+    if rank == 0:
+        M, D, F = B * 197, m["hidden"], m["mlp"]
+        a = torch.randn(M, D, device=dev).to(torch.bfloat16)
+        w = (torch.randn(F, D, device=dev) * 0.02).to(torch.bfloat16)
+        bias = torch.zeros(F, device=dev)
+        for _ in range(3):
+            ops.gemm_nt(a, w, ops.EPI_GELU, bias=bias)
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        outs = [torch.empty(M, F, dtype=torch.bfloat16, device=dev) for _ in range(2)]
+        from touhouimageclassification_amd._lib import call, current_stream
+        e0.record()
+        for _ in range(reps):
+            call("tic_gemm_nt_bf16", a.data_ptr(), w.data_ptr(), M, F, D, 1, bias.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
+                 None, None, None, None, 0, current_stream())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        dom = dict(kernel="gemm_nt_kernel<GELU>", shape=[M, F, D], ms=round(ms, 4),
+                   tflops=round(2.0 * M * F * D / (ms * 1e-3) / 1e12, 1))
+
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        fl = train_flops_per_image(m, C)
+        achieved = ips * fl / world / 1e12
+        out = {
+            "metric": f"images/sec ViT-{'L' if args.model == 'large' else 'B'}/16 224px bf16 fine-tune",
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"ViT-{args.model}/16 224px C={C} fine-tune step (fwd+CE+bwd+AdamW{'+grad all-reduce' if world > 1 else ''})",
+                       "per_gpu_batch": B, "global_batch": B * world, "tokens": 197, "parallelism": f"dp{world}",
+                       "optimizer": "AdamW lr=1e-5 wd=0.01 (fused, fp32 master weights)", "step_driver": "autograd" if args.autograd else "fused"},
+            "loss": round(loss_v, 5),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "flops_per_image": fl, "dominant_kernel": dom},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model, C)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,8 +134,9 @@ typedef struct {
     void* workspace;      /* ws_bytes */
 } TicVitState;
 
-/* refresh w16 / wT16 from params (after load_state_dict or an external optimizer step) */
-int tic_vit_refresh_weights(const TicVitState* st, tic_stream_t stream);
+/* refresh the bf16 GEMM operands from params (after load_state_dict or an external optimizer step);
+ * transposes_only != 0 when w16 is already current (tic_adamw wrote it) and only wT16 needs rebuilding */
+int tic_vit_refresh_weights(const TicVitState* st, int transposes_only, tic_stream_t stream);
 /* pixel_values [B,3,224,224] fp32 -> logits [B,C] fp32 (also kept in the workspace) */
 int tic_vit_forward(const TicVitState* st, const float* pixel_values, float* logits_out, tic_stream_t stream);
 /* backward in three phases so the caller can overlap gradient all-reduce per bucket:

@@ -52,10 +52,16 @@ struct Block {
 
 struct Fiber {
     ucontext_t ctx;
-    std::vector<char> stack;
+    char* stack = nullptr;   // from a process-lifetime pool (no per-block allocation / zero-fill)
     int tid = 0;
     bool done = false;
 };
+static const size_t kStackBytes = 256 * 1024;
+inline char* pooled_stack(int tid) {
+    static std::vector<char*> pool;
+    while ((int)pool.size() <= tid) pool.push_back((char*)malloc(kStackBytes));
+    return pool[tid];
+}
 
 struct State {
     Block* blk = nullptr;
@@ -91,10 +97,10 @@ inline void run_block(Block& b) {
     for (int t = 0; t < b.nthreads; ++t) {
         Fiber& f = fibers[t];
         f.tid = t;
-        f.stack.resize(256 * 1024);
+        f.stack = pooled_stack(t);
         getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack.data();
-        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStackBytes;
         f.ctx.uc_link = &s.sched;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
     }

@@ -38,3 +38,16 @@ def bf(t):
 def bfr(t):
     """bf16 round-trip, value kept in fp32."""
     return t.to(torch.bfloat16).to(torch.float32)
+
+
+class SimBackend:
+    """Engine backend that routes the C ABI to the CPU simulator build (tests only)."""
+
+    def call(self, name, *args):
+        call(name, *args)
+
+    def stream(self):
+        return None
+
+    def check_tensor(self, t):
+        assert not t.is_cuda

@@ -1,0 +1,58 @@
+"""GPU parity tests of every C-ABI operator (libtic_hip.so on a real MI355X) against plain torch
+fp32 math on the same device, at hot-path shapes (ViT-B / ViT-L token matrices, N = 197 ragged M)
+and at ragged edge shapes.  Tolerances are bf16-level and written in tests/kernel_checks.py."""
+import pytest
+import torch
+
+from tests import kernel_checks as kc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def env():
+    from touhouimageclassification_amd._lib import call, current_stream
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return kc.Env("cuda", call, stream=current_stream)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 128, 64), (130, 256, 192), (12608, 3072, 1024), (1970, 768, 3072), (197 * 3 + 1, 1024, 4096)])
+def test_gemm_nt_bias_bf16(env, M, N, K):
+    kc.check_gemm_nt_bias_bf16(env, M, N, K)
+
+
+@pytest.mark.parametrize("N,K,imgs,Pn", [(128, 128, 3, 50), (1024, 768, 16, 196), (4096, 1024, 7, 197)])
+def test_gemm_nt_epilogues(env, N, K, imgs, Pn):
+    kc.check_gemm_nt_gelu_resid_dgelu_patch(env, N, K, imgs, Pn)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 256), (200, 128, 256), (333, 256, 128), (12608, 1024, 1024), (1970, 3072, 768), (3940, 1024, 4096)])
+def test_gemm_tn(env, M, N, K):
+    kc.check_gemm_tn(env, M, N, K)
+
+
+@pytest.mark.parametrize("D,rows", [(128, 9), (768, 1001), (1024, 12608)])
+def test_layernorm_fwd_bwd(env, D, rows):
+    kc.check_layernorm_fwd_bwd(env, D, rows)
+
+
+def test_layernorm_strided_cls_rows(env):
+    kc.check_layernorm_strided_cls_rows(env)
+
+
+@pytest.mark.parametrize("B,H,N", [(1, 2, 197), (2, 1, 50), (8, 16, 197), (3, 12, 197)])
+def test_attention_fwd_bwd(env, B, H, N):
+    kc.check_attention_fwd_bwd(env, B, H, N)
+
+
+def test_elementwise_ops(env):
+    kc.check_elementwise_ops(env)
+
+
+def test_adamw_matches_torch(env):
+    kc.check_adamw_matches_torch(env)
+
+
+@pytest.mark.parametrize("soft", [False, True])
+def test_head_and_xent(env, soft):
+    kc.check_head_and_xent(env, soft)

@@ -1,202 +1,57 @@
 """CPU checks of the HIP kernel sources through the wave-lockstep simulator (no GPU needed).
 
-These validate indexing / lane maps / swizzles / ragged-edge handling of every kernel on tiny
-shapes against plain torch fp32 math.  The same checks run against the real library on the GPU
+The kernel SOURCE that ships in libtic_hip.so is compiled against tests/sim/sim_runtime.h and run on
+tiny shapes: this validates indexing, MFMA / transposed-LDS lane maps, swizzles and ragged-edge
+handling against plain torch fp32 math.  The same checks run against the real library on the GPU
 box in test_gpu_ops.py.
 """
-import math
-
 import pytest
-import torch
 
-from tests.simlib import bf, bfr, call, ptr
-
-torch.manual_seed(0)
+from tests import kernel_checks as kc
+from tests.simlib import call
 
 
-def rnd(*shape, scale=1.0):
-    return torch.randn(*shape) * scale
+@pytest.fixture()
+def env():
+    return kc.Env("cpu", call)
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 128, 64), (130, 256, 192)])
-def test_gemm_nt_bias_bf16(M, N, K):
-    A, B, bias = bf(rnd(M, K)), bf(rnd(N, K)), rnd(N)
-    out = torch.full((M, N), 7.0).to(torch.bfloat16)
-    call("tic_gemm_nt_bf16", ptr(A), ptr(B), M, N, K, 0, ptr(bias), ptr(out), None, None, None, None, None, 0, None)
-    ref = A.float() @ B.float().t() + bias
-    torch.testing.assert_close(out.float(), ref, atol=0.06, rtol=0.02)
+def test_gemm_nt_bias_bf16(env, M, N, K):
+    kc.check_gemm_nt_bias_bf16(env, M, N, K)
 
 
-def test_gemm_nt_gelu_resid_dgelu_patch():
-    M, N, K = 150, 128, 128
-    A, B, bias = bf(rnd(M, K, scale=0.3)), bf(rnd(N, K, scale=0.3)), rnd(N, scale=0.1)
-    u, g = torch.empty(M, N, dtype=torch.bfloat16), torch.empty(M, N, dtype=torch.bfloat16)
-    call("tic_gemm_nt_bf16", ptr(A), ptr(B), M, N, K, 1, ptr(bias), ptr(u), ptr(g), None, None, None, None, 0, None)
-    ref_u = bfr(A.float() @ B.float().t() + bias)
-    torch.testing.assert_close(u.float(), ref_u, atol=0.03, rtol=0.02)
-    torch.testing.assert_close(g.float(), torch.nn.functional.gelu(u.float()), atol=0.02, rtol=0.02)
-    # residual
-    resid, out = rnd(M, N), torch.empty(M, N)
-    call("tic_gemm_nt_bf16", ptr(A), ptr(B), M, N, K, 2, ptr(bias), None, None, ptr(out), ptr(resid), None, None, 0, None)
-    torch.testing.assert_close(out, resid + ref_u, atol=0.03, rtol=0.02)
-    # dgelu
-    d = torch.empty(M, N, dtype=torch.bfloat16)
-    call("tic_gemm_nt_bf16", ptr(A), ptr(B), M, N, K, 3, None, ptr(d), None, None, None, ptr(u), None, 0, None)
-    uu = u.float().requires_grad_(True)
-    torch.nn.functional.gelu(uu).backward(bfr(A.float() @ B.float().t()))
-    torch.testing.assert_close(d.float(), uu.grad, atol=0.03, rtol=0.03)
-    # patch epilogue: M = images * patches, rows remapped past the CLS slot
-    imgs, Pn = 3, 50
-    pos = rnd(Pn + 1, N)
-    h = torch.zeros(imgs * (Pn + 1), N)
-    call("tic_gemm_nt_bf16", ptr(A), ptr(B), imgs * Pn, N, K, 4, ptr(bias), None, None, ptr(h), None, None, ptr(pos), Pn, None)
-    h = h.view(imgs, Pn + 1, N)
-    assert h[:, 0].abs().max() == 0
-    torch.testing.assert_close(h[:, 1:], ref_u.view(imgs, Pn, N) + pos[1:], atol=0.03, rtol=0.02)
+def test_gemm_nt_epilogues(env):
+    kc.check_gemm_nt_gelu_resid_dgelu_patch(env)
 
 
 @pytest.mark.parametrize("M", [64, 200, 333])
-def test_gemm_tn(M):
-    N, K = 128, 256
-    A, B = bf(rnd(M, N)), bf(rnd(M, K))
-    Cm = rnd(N, K)
-    ref = Cm + A.float().t() @ B.float()
-    call("tic_gemm_tn_bf16", ptr(A), ptr(B), ptr(Cm), M, N, K, None)
-    torch.testing.assert_close(Cm, ref, atol=2e-3, rtol=1e-3)
+def test_gemm_tn(env, M):
+    kc.check_gemm_tn(env, M)
 
 
 @pytest.mark.parametrize("D", [128, 768, 1024])
-def test_layernorm_fwd_bwd(D):
-    rows = 9
-    x, gamma, beta = rnd(rows, D) * 2 + 0.5, 1 + rnd(D, scale=0.1), rnd(D, scale=0.1)
-    y = torch.empty(rows, D, dtype=torch.bfloat16)
-    mean, rstd = torch.empty(rows), torch.empty(rows)
-    call("tic_layernorm_fwd", ptr(x), D, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, D, 1e-12, None)
-    xr = x.clone().requires_grad_(True)
-    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-12)
-    torch.testing.assert_close(y.float(), ref.detach(), atol=0.02, rtol=0.01)
-    torch.testing.assert_close(mean, x.mean(-1), atol=1e-5, rtol=1e-5)
-    dy = bf(rnd(rows, D))
-    ref.backward(dy.float())
-    dres = rnd(rows, D)
-    dx, dxb = torch.empty(rows, D), torch.empty(rows, D, dtype=torch.bfloat16)
-    dg, db = torch.zeros(D), torch.zeros(D)
-    call("tic_layernorm_bwd", ptr(dy), ptr(x), D, ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dxb), ptr(dg), ptr(db), rows, D, None)
-    torch.testing.assert_close(dx, dres + xr.grad, atol=1e-4, rtol=1e-4)
-    torch.testing.assert_close(dxb.float(), bfr(dx), atol=0, rtol=0)
-    torch.testing.assert_close(dg, gr.grad, atol=1e-4, rtol=1e-4)
-    torch.testing.assert_close(db, br.grad, atol=1e-4, rtol=1e-4)
+def test_layernorm_fwd_bwd(env, D):
+    kc.check_layernorm_fwd_bwd(env, D)
 
 
-def test_layernorm_strided_cls_rows():
-    B, N, D = 3, 5, 128
-    h = rnd(B, N, D)
-    gamma, beta = 1 + rnd(D, scale=0.1), rnd(D, scale=0.1)
-    y = torch.empty(B, D, dtype=torch.bfloat16)
-    mean, rstd = torch.empty(B), torch.empty(B)
-    call("tic_layernorm_fwd", ptr(h), N * D, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), B, D, 1e-12, None)
-    torch.testing.assert_close(y.float(), torch.nn.functional.layer_norm(h[:, 0], (D,), gamma, beta, 1e-12), atol=0.02, rtol=0.01)
-
-
-def _attn_ref(qkv, B, H, N):
-    D = H * 64
-    q, k, v = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
-    s = (q @ k.transpose(-1, -2)) * 0.125
-    p = torch.softmax(s, -1)
-    o = (p @ v).permute(0, 2, 1, 3).reshape(B * N, D)
-    return o, torch.logsumexp(s, -1)
+def test_layernorm_strided_cls_rows(env):
+    kc.check_layernorm_strided_cls_rows(env)
 
 
 @pytest.mark.parametrize("B,H,N", [(1, 2, 197), (2, 1, 50)])
-def test_attention_fwd_bwd(B, H, N):
-    D = H * 64
-    qkv = bf(rnd(B * N, 3 * D))
-    o = torch.empty(B * N, D, dtype=torch.bfloat16)
-    lse = torch.empty(B * H, N)
-    call("tic_attention_fwd", ptr(qkv), ptr(o), ptr(lse), B, H, N, 0.125, None)
-    qr = qkv.float().requires_grad_(True)
-    o_ref, lse_ref = _attn_ref(qr, B, H, N)
-    torch.testing.assert_close(o.float(), o_ref.detach(), atol=0.02, rtol=0.02)
-    torch.testing.assert_close(lse.view(B, H, N), lse_ref.detach(), atol=2e-3, rtol=1e-3)
-    do = bf(rnd(B * N, D))
-    o_ref.backward(do.float())
-    dqkv = torch.full((B * N, 3 * D), 9.0).to(torch.bfloat16)
-    call("tic_attention_bwd", ptr(qkv), ptr(o), ptr(lse), ptr(do), ptr(dqkv), B, H, N, 0.125, None)
-    torch.testing.assert_close(dqkv.float(), qr.grad, atol=0.03, rtol=0.05)
+def test_attention_fwd_bwd(env, B, H, N):
+    kc.check_attention_fwd_bwd(env, B, H, N)
 
 
-def test_elementwise_ops():
-    # patchify
-    B, C, img, patch = 2, 3, 32, 16
-    x = rnd(B, C, img, img)
-    G = img // patch
-    P = torch.empty(B * G * G, C * patch * patch, dtype=torch.bfloat16)
-    call("tic_patchify", ptr(x), ptr(P), B, C, img, patch, None)
-    ref = x.reshape(B, C, G, patch, G, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * G * G, -1)
-    torch.testing.assert_close(P.float(), bfr(ref), atol=0, rtol=0)
-    # colsum
-    M, N = 77, 384
-    a = bf(rnd(M, N))
-    out = torch.ones(N)
-    call("tic_colsum_bf16", ptr(a), ptr(out), M, N, None)
-    torch.testing.assert_close(out, 1 + a.float().sum(0), atol=1e-3, rtol=1e-4)
-    # casts
-    w = rnd(128, 192)
-    w16, wT = torch.empty(128, 192, dtype=torch.bfloat16), torch.empty(192, 128, dtype=torch.bfloat16)
-    call("tic_cast_bf16", ptr(w), ptr(w16), w.numel(), None)
-    call("tic_cast_transpose_bf16", ptr(w), ptr(wT), 128, 192, None)
-    assert torch.equal(w16, bf(w)) and torch.equal(wT, bf(w).t().contiguous())
-    # embed cls / bwd / gather
-    Bn, N_, D = 2, 5, 128
-    cls, pos, h = rnd(D), rnd(N_, D), torch.zeros(Bn, N_, D)
-    call("tic_embed_cls", ptr(cls), ptr(pos), ptr(h), Bn, N_, D, None)
-    torch.testing.assert_close(h[:, 0], (cls + pos[0]).expand(Bn, D))
-    dh = rnd(Bn, N_, D)
-    dcls, dpos = torch.zeros(D), torch.zeros(N_, D)
-    call("tic_embed_bwd", ptr(dh), ptr(dcls), ptr(dpos), Bn, N_, D, None)
-    torch.testing.assert_close(dcls, dh[:, 0].sum(0))
-    torch.testing.assert_close(dpos, dh.sum(0))
-    g = torch.empty(Bn * (N_ - 1), D, dtype=torch.bfloat16)
-    call("tic_gather_patch_rows", ptr(dh), ptr(g), Bn, N_, D, None)
-    assert torch.equal(g, bf(dh[:, 1:].reshape(-1, D)))
+def test_elementwise_ops(env):
+    kc.check_elementwise_ops(env)
 
 
-def test_adamw_matches_torch():
-    n = 1000
-    p0, g = rnd(n), rnd(n)
-    ref = torch.nn.Parameter(p0.clone())
-    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.01)
-    p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
-    w16 = torch.empty(n, dtype=torch.bfloat16)
-    for step in (1, 2, 3):
-        gs = g * step   # keep alive across the call
-        ref.grad = gs
-        opt.step()
-        call("tic_adamw", ptr(p), ptr(gs), ptr(m), ptr(v), ptr(w16), n, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, None)
-    torch.testing.assert_close(p, ref.detach(), atol=1e-6, rtol=1e-5)
-    assert torch.equal(w16, bf(p))
+def test_adamw_matches_torch(env):
+    kc.check_adamw_matches_torch(env)
 
 
 @pytest.mark.parametrize("soft", [False, True])
-def test_head_and_xent(soft):
-    B, Cc, D = 5, 10, 128
-    z, W, b = bf(rnd(B, D)), rnd(Cc, D, scale=0.1), rnd(Cc, scale=0.1)
-    logits = torch.empty(B, Cc)
-    call("tic_head_fwd", ptr(z), ptr(W), ptr(b), ptr(logits), B, Cc, D, None)
-    torch.testing.assert_close(logits, bfr(z.float() @ bfr(W).t() + bfr(b)), atol=0.02, rtol=0.01)
-    y = torch.randint(0, Cc, (B,))
-    t = torch.softmax(rnd(B, Cc), -1)
-    lr = logits.clone().requires_grad_(True)
-    loss_ref = torch.nn.functional.cross_entropy(lr, t if soft else y)
-    loss_ref.backward()
-    loss, dl = torch.zeros(1), torch.empty(B, Cc)
-    call("tic_softmax_xent", ptr(logits), None if soft else ptr(y), ptr(t) if soft else None, ptr(loss), ptr(dl), B, Cc, 1.0, None)
-    torch.testing.assert_close(loss[0], loss_ref.detach(), atol=1e-5, rtol=1e-5)
-    torch.testing.assert_close(dl, lr.grad, atol=1e-6, rtol=1e-4)
-    dz = torch.empty(B, D, dtype=torch.bfloat16)
-    dW, db = torch.zeros(Cc, D), torch.zeros(Cc)
-    call("tic_head_bwd", ptr(dl), ptr(z), ptr(W), ptr(dz), ptr(dW), ptr(db), B, Cc, D, None)
-    torch.testing.assert_close(dz.float(), bfr(dl) @ bfr(W), atol=1e-3, rtol=0.02)
-    torch.testing.assert_close(dW, bfr(dl).t() @ z.float(), atol=1e-4, rtol=1e-3)
-    torch.testing.assert_close(db, bfr(dl).sum(0), atol=1e-5, rtol=1e-4)
+def test_head_and_xent(env, soft):
+    kc.check_head_and_xent(env, soft)

@@ -1,0 +1,75 @@
+"""Whole-model check on CPU: the product's Python surface (ViT factory, module tree, engine, phase
+drivers in C) driven through the simulator build, against the oracle and the HF-pinned golden file."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as vo
+from tests.simlib import SimBackend
+from touhouimageclassification_amd.ViT.model import ViT
+
+
+def _tiny(gold):
+    spec = vo.ViTSpec(**vo.VIT_TINY, num_labels=10)
+    params = {k[len("param/"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("param/")}
+    return spec, params
+
+
+def test_state_dict_surface():
+    m = ViT(10, pretrained=False, model_name="tiny", backend=SimBackend())
+    spec = vo.ViTSpec(**vo.VIT_TINY, num_labels=10)
+    names = [n for n, _ in vo.param_shapes(spec)]
+    sd = {k: v.clone() for k, v in m.state_dict().items()}   # state_dict() aliases the flat buffer
+    assert set(sd.keys()) == set(names)
+    for n, shp in vo.param_shapes(spec):
+        assert tuple(sd[n].shape) == shp
+    assert m.config.image_size == 224
+    assert sum(p.numel() for p in m.parameters()) == sum(int(np.prod(s)) for _, s in vo.param_shapes(spec))
+    assert len(list(m.base_model.parameters())) == len(names) - 2
+    # 4.x checkpoint keys + Lightning prefix load too
+    old = {}
+    for k, v in sd.items():
+        k = k.replace("vit.layers.", "vit.encoder.layer.").replace(".attention.q_proj.", ".attention.attention.query.")
+        k = k.replace(".attention.k_proj.", ".attention.attention.key.").replace(".attention.v_proj.", ".attention.attention.value.")
+        k = k.replace(".attention.o_proj.", ".attention.output.dense.").replace(".mlp.fc1.", ".intermediate.dense.").replace(".mlp.fc2.", ".output.dense.")
+        old["vit." + k] = v + 1
+    m.load_state_dict(old)
+    torch.testing.assert_close(m.state_dict()["vit.layers.1.mlp.fc2.bias"], sd["vit.layers.1.mlp.fc2.bias"] + 1)
+    with pytest.raises(FileNotFoundError):
+        ViT(10, pretrained=True, model_name="google/vit-base-patch16-224", backend=SimBackend())
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 1, 224, 224))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 32, 32))
+
+
+def test_tiny_vit_step_matches_golden(golden_dir):
+    gold = np.load(f"{golden_dir}/vit_tiny.npz")
+    spec, params = _tiny(gold)
+    m = ViT(10, pretrained=False, model_name="tiny", backend=SimBackend())
+    m.load_state_dict(params)
+    B = 2
+    x = torch.from_numpy(gold["x"][:B])
+    y = torch.from_numpy(gold["y"][:B])
+    # oracle with the bf16 rounding points of autocast == what the kernels compute
+    o_logits, o_loss, o_grads = vo.loss_and_grads(params, x, y, spec, emulate_autocast=True)
+    f_logits, _, f_grads = vo.loss_and_grads(params, x, y, spec)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-5, weight_decay=0.01)
+    opt.zero_grad()
+    logits = m(x).logits
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    torch.testing.assert_close(logits, o_logits, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(logits, f_logits, atol=3e-2, rtol=3e-2)          # fp32 reference path (golden == HF)
+    torch.testing.assert_close(f_logits, torch.from_numpy(gold["logits_hard"][:B]), atol=1e-5, rtol=1e-5)
+    gmax = max(g.norm().item() for g in f_grads.values())
+    for k, p in m.named_parameters():
+        ref = f_grads[k]
+        err = (p.grad - ref).norm().item()
+        assert err <= 0.08 * ref.norm().item() + 2e-3 * gmax, (k, err, ref.norm().item())
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    opt.step()
+    logits2 = m(x).logits   # weights refreshed automatically after the optimizer step
+    assert not torch.equal(logits2, logits)
+    for k, p in m.named_parameters():
+        assert (p.detach() - before[k]).abs().max() <= 1.2e-5 + 1e-7

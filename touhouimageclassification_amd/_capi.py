@@ -58,7 +58,7 @@ SIGNATURES = {
     "tic_head_bwd": ([P, P, P, P, P, P, I, I, I, P], I),
     "tic_softmax_xent": ([P, P, P, P, P, I, I, F, P], I),
     "tic_vit_layout": ([C.POINTER(TicVitDims), C.POINTER(TicVitLayout)], I),
-    "tic_vit_refresh_weights": ([C.POINTER(TicVitState), P], I),
+    "tic_vit_refresh_weights": ([C.POINTER(TicVitState), I, P], I),
     "tic_vit_forward": ([C.POINTER(TicVitState), P, P, P], I),
     "tic_vit_backward_head": ([C.POINTER(TicVitState), P, P], I),
     "tic_vit_backward_layer": ([C.POINTER(TicVitState), I, P], I),

@@ -49,7 +49,7 @@ def build_sim(force: bool = False) -> str:
     deps = _sources() + [os.path.join(SIM_DIR, "sim_runtime.h"), os.path.join(SIM_DIR, "tic_sim.cpp")]
     if not force and _newer(SIM_LIB, deps):
         return SIM_LIB
-    cmd = [os.path.join(ROCM, "lib", "llvm", "bin", "clang++"), "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared",
+    cmd = [os.path.join(ROCM, "lib", "llvm", "bin", "clang++"), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared",
            "-DTIC_SIM", "-I", SIM_DIR, "-I", CSRC, os.path.join(SIM_DIR, "tic_sim.cpp"), "-o", SIM_LIB]
     subprocess.run(cmd, check=True)
     return SIM_LIB

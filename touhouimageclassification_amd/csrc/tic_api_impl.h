@@ -351,11 +351,11 @@ static int vit_ctx(const TicVitState* st, VitCtx& c) {
     return TIC_OK;
 }
 
-extern "C" int tic_vit_refresh_weights(const TicVitState* st, tic_stream_t s) {
+extern "C" int tic_vit_refresh_weights(const TicVitState* st, int transposes_only, tic_stream_t s) {
     VitCtx c;
     TIC_TRY(vit_ctx(st, c));
     const TicVitLayout& y = c.lay;
-    TIC_TRY(tic_cast_bf16(c.P, c.W16, y.n_params, s));
+    if (!transposes_only) TIC_TRY(tic_cast_bf16(c.P, c.W16, y.n_params, s));
     for (long l = 0; l < c.L; ++l) {
         const float* lp = c.P + y.layer0 + l * y.layer_stride;
         bf16_t* lt = c.WT + l * y.t_layer_stride;
