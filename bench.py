@@ -34,11 +34,23 @@ def train_flops_per_image(m, C):
     return 3.0 * fwd
 
 
-def cpu_baseline(model_key, C, seconds_budget=25.0):
+def host_cores():
+    """threads we may actually use: cgroup quota / affinity, not the machine's core count"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:   # noqa: BLE001
+        pass
+    return max(1, min(n, 16))   # a 1-GPU box owns a 16-core share
+
+
+def cpu_baseline(model_key, C, seconds_budget=20.0):
     """oracle fwd+bwd+AdamW (fp32, B=4) on the host cores: a reported baseline, not a target"""
     from oracle import vit_oracle as vo
     m = MODELS[model_key]
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     spec = vo.ViTSpec(hidden=m["hidden"], layers=m["layers"], heads=m["heads"], mlp=m["mlp"], num_labels=C)
     params = vo.init_params(spec, seed=0)
@@ -54,10 +66,11 @@ def cpu_baseline(model_key, C, seconds_budget=25.0):
         for k in params:
             vo.adamw_step(params[k], grads[k], mom[k], var[k], i, lr=1e-5, wd=0.01)
 
+    print(f"[bench] cpu baseline on {cores} threads ...", file=sys.stderr, flush=True)
     step(1)   # warm-up
     t0 = time.perf_counter()
     n = 0
-    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
+    while n < 1 or (time.perf_counter() - t0 < seconds_budget and n < 6):
         n += 1
         step(n + 1)
     dt = time.perf_counter() - t0
@@ -118,6 +131,8 @@ def main():
             return loss
         return fused_train_step(model, opt, x, y, sync)[0]
 
+    if rank == 0:
+        print(f"[bench] ViT-{args.model} B={B}/GPU world={world}: warm-up", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -135,6 +150,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = tt.item()
     loss_v = float(loss)
+    if rank == 0:
+        print(f"[bench] {args.steps} steps in {dt:.3f}s = {world * B * args.steps / dt:.1f} img/s, loss {loss_v:.4f}", file=sys.stderr, flush=True)
 
     # dominant kernel on its own: gemm_nt at the fc1 shape [M,D] x [F,D]^T with the GELU epilogue,
     # HIP events on the stream it is launched on (torch's current stream)

@@ -67,8 +67,9 @@ def test_tiny_step_matches_golden_and_oracle(golden_dir):
         ref = torch.from_numpy(gold[f"after_adamw/{k}"])
         # every element moves by ~lr; direction can flip only where |g| is at the bf16 noise floor
         assert (p.detach().cpu() - ref).abs().max().item() <= 2.1e-5, k
-        agree = ((p.detach().cpu() - params[k]).sign() == (ref - params[k]).sign()).float().mean().item()
-        assert agree > 0.9, (k, agree)
+        if np.linalg.norm(gold[f"grad_hard/{k}"]) > 1e-3 * gmax:   # k_proj.bias: analytically zero gradient = pure noise
+            agree = ((p.detach().cpu() - params[k]).sign() == (ref - params[k]).sign()).float().mean().item()
+            assert agree > 0.9, (k, agree)
 
 
 @pytest.mark.parametrize("tag,base,C,B,seed", [("base_c10_b4", "base", 10, 4, 10), ("large_c120_b2", "large", 120, 2, 20)])

@@ -23,6 +23,9 @@ def lib() -> ctypes.CDLL:
             raise TicLibraryError(
                 f"{path} is missing and could not be built with hipcc ({e}). The TIC hot path has no CPU or "
                 "PyTorch fallback: build it with `python -m touhouimageclassification_amd.build hip`.") from e
+    # torch bundles its own libamdhip64.so.7; it must be in the process BEFORE our library so that our
+    # NEEDED libamdhip64.so.7 resolves to the SAME runtime (one HIP context, shared streams / pointers)
+    import torch  # noqa: F401
     try:
         handle = ctypes.CDLL(path)
     except OSError as e:
