@@ -31,6 +31,8 @@ typedef void* tic_stream_t; /* hipStream_t */
 #define TIC_ABI_VERSION 1
 int tic_version(void);
 const char* tic_last_error_string(void);
+/* process-wide tuning knob for A/B measurements: "gemm_tile" = 0 (auto) | 128 | 256 */
+int tic_set_option(const char* name, int value);
 
 /* GEMM epilogues (fused into the MFMA kernel's store) */
 #define TIC_EPI_BF16 0  /* out = bf16(acc + bias)                                   Linear            */

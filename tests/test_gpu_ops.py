@@ -56,3 +56,23 @@ def test_adamw_matches_torch(env):
 @pytest.mark.parametrize("soft", [False, True])
 def test_head_and_xent(env, soft):
     kc.check_head_and_xent(env, soft)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (12608, 1024, 4096), (16351, 3072, 1024), (1000, 4096, 1024)])
+def test_gemm_nt256_pipelined(env, M, N, K):
+    """the deep-pipelined 256x256 kernel forced on: same checks + bitwise equality with the 128x128 kernel
+    (identical fp32 accumulation order, so any difference is a pipeline race)."""
+    from touhouimageclassification_amd._lib import call
+    from touhouimageclassification_amd import ops
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * 0.1).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda")
+    try:
+        call("tic_set_option", b"gemm_tile", 128)
+        ref = ops.gemm_nt(a, w, ops.EPI_BF16, bias=bias)
+        call("tic_set_option", b"gemm_tile", 256)
+        kc.check_gemm_nt_bias_bf16(env, M, N, K)
+        for _ in range(5):
+            assert torch.equal(ops.gemm_nt(a, w, ops.EPI_BF16, bias=bias), ref)
+    finally:
+        call("tic_set_option", b"gemm_tile", 0)

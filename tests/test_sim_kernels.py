@@ -55,3 +55,15 @@ def test_adamw_matches_torch(env):
 @pytest.mark.parametrize("soft", [False, True])
 def test_head_and_xent(env, soft):
     kc.check_head_and_xent(env, soft)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (520, 256, 256), (257, 512, 128)])
+def test_gemm_nt256_pipelined(env, M, N, K):
+    """the 256x256 deep-pipelined kernel (forced), incl. ragged M, nk = 1 and odd/even K-tile counts"""
+    call("tic_set_option", b"gemm_tile", 256)
+    try:
+        kc.check_gemm_nt_bias_bf16(env, M, N, K)
+        if K == 256:
+            kc.check_gemm_nt_gelu_resid_dgelu_patch(env, N=256, K=192, imgs=3, Pn=50)
+    finally:
+        call("tic_set_option", b"gemm_tile", 0)

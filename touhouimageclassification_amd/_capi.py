@@ -40,6 +40,7 @@ class TicVitState(C.Structure):
 SIGNATURES = {
     "tic_version": ([], I),
     "tic_last_error_string": ([], C.c_char_p),
+    "tic_set_option": ([C.c_char_p, I], I),
     "tic_gemm_nt_bf16": ([P, P, I, I, I, I, P, P, P, P, P, P, P, I, P], I),
     "tic_gemm_tn_bf16": ([P, P, P, I, I, I, P], I),
     "tic_layernorm_fwd": ([P, L, P, P, P, P, P, I, I, F, P], I),

@@ -50,6 +50,49 @@ TIC_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& tm, in
     tn = in_group / gsize;
 }
 
+// one lane's 4 consecutive outputs (row m, columns n..n+3) of any epilogue
+template <int EPI>
+TIC_DEV void gemm_epilogue_store(const GemmNtParams& p, int m, int n, f32x4 v) {
+    if (EPI != TIC_EPI_DGELU && p.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+        v += b;
+    }
+    const size_t o = (size_t)m * p.N + n;
+    if (EPI == TIC_EPI_BF16) {
+        *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    } else if (EPI == TIC_EPI_GELU) {
+        float u[4], g[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            u[r] = bfround(v[r]);
+            g[r] = gelu_erf(u[r]);
+        }
+        *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(u[0], u[1]), pack2bf(u[2], u[3])};
+        *reinterpret_cast<u32x2*>(p.out2 + o) = u32x2{pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
+    } else if (EPI == TIC_EPI_RESID) {
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + o);
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = rs[r] + bfround(v[r]);
+        *reinterpret_cast<f32x4*>(p.out_f32 + o) = y;
+    } else if (EPI == TIC_EPI_DGELU) {
+        const u32x2 ur = *reinterpret_cast<const u32x2*>(p.aux + o);
+        const float u0 = bf2f((bf16_t)(ur[0] & 0xffff)), u1 = bf2f((bf16_t)(ur[0] >> 16));
+        const float u2 = bf2f((bf16_t)(ur[1] & 0xffff)), u3 = bf2f((bf16_t)(ur[1] >> 16));
+        const float d0 = bfround(v[0]) * gelu_erf_grad(u0), d1 = bfround(v[1]) * gelu_erf_grad(u1);
+        const float d2 = bfround(v[2]) * gelu_erf_grad(u2), d3 = bfround(v[3]) * gelu_erf_grad(u3);
+        *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
+    } else if (EPI == TIC_EPI_PATCH) {
+        const int img = m / p.patches, pi = m - img * p.patches;
+        const size_t orow = (size_t)img * (p.patches + 1) + 1 + pi;
+        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.rowtab + (size_t)(1 + pi) * p.N + n);
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = bfround(v[r]) + pe[r];
+        *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.N + n) = y;
+    }
+}
+
 #define GEMM_BM 128
 #define GEMM_BN 128
 #define GEMM_BK 64
@@ -135,48 +178,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
         const int m = m0 + wm * 64 + mt * 16 + (l & 15);
         if (m >= p.M) continue;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + 4 * (l >> 4);
-            f32x4 v = acc[mt][nt];
-            if (EPI != TIC_EPI_DGELU && p.bias) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-                v += b;
-            }
-            const size_t o = (size_t)m * p.N + n;
-            if (EPI == TIC_EPI_BF16) {
-                *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-            } else if (EPI == TIC_EPI_GELU) {
-                float u[4], g[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    u[r] = bfround(v[r]);
-                    g[r] = gelu_erf(u[r]);
-                }
-                *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(u[0], u[1]), pack2bf(u[2], u[3])};
-                *reinterpret_cast<u32x2*>(p.out2 + o) = u32x2{pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
-            } else if (EPI == TIC_EPI_RESID) {
-                const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + o);
-                f32x4 y;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = rs[r] + bfround(v[r]);
-                *reinterpret_cast<f32x4*>(p.out_f32 + o) = y;
-            } else if (EPI == TIC_EPI_DGELU) {
-                const u32x2 ur = *reinterpret_cast<const u32x2*>(p.aux + o);
-                const float u0 = bf2f((bf16_t)(ur[0] & 0xffff)), u1 = bf2f((bf16_t)(ur[0] >> 16));
-                const float u2 = bf2f((bf16_t)(ur[1] & 0xffff)), u3 = bf2f((bf16_t)(ur[1] >> 16));
-                const float d0 = bfround(v[0]) * gelu_erf_grad(u0), d1 = bfround(v[1]) * gelu_erf_grad(u1);
-                const float d2 = bfround(v[2]) * gelu_erf_grad(u2), d3 = bfround(v[3]) * gelu_erf_grad(u3);
-                *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
-            } else if (EPI == TIC_EPI_PATCH) {
-                const int img = m / p.patches, pi = m - img * p.patches;
-                const size_t orow = (size_t)img * (p.patches + 1) + 1 + pi;
-                const f32x4 pe = *reinterpret_cast<const f32x4*>(p.rowtab + (size_t)(1 + pi) * p.N + n);
-                f32x4 y;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = bfround(v[r]) + pe[r];
-                *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.N + n) = y;
-            }
-        }
+        for (int nt = 0; nt < 4; ++nt) gemm_epilogue_store<EPI>(p, m, n0 + wn * 64 + nt * 16 + 4 * (l >> 4), acc[mt][nt]);
     }
 }
 

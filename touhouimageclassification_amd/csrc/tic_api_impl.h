@@ -11,6 +11,7 @@
 #include "attention.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "gemm256.h"
 #include "norm.h"
 
 static thread_local char g_tic_err[512] = "";
@@ -33,6 +34,16 @@ static int tic_after_launch(const char* what) {
     return TIC_OK;
 }
 
+// tuning knobs (process-wide, for A/B measurements and tests): "gemm_tile" = 0 (auto) | 128 | 256
+static int g_opt_gemm_tile = 0;
+extern "C" int tic_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) {
+        g_opt_gemm_tile = value;
+        return TIC_OK;
+    }
+    return tic_fail(TIC_EINVAL, "set_option: unknown option/value %s=%d", name ? name : "(null)", value);
+}
+
 extern "C" int tic_version(void) { return TIC_ABI_VERSION; }
 extern "C" const char* tic_last_error_string(void) { return g_tic_err; }
 
@@ -45,43 +56,51 @@ extern "C" int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     TIC_REQUIRE(N % 128 == 0 && K % 64 == 0, "gemm_nt: need N %% 128 == 0 and K %% 64 == 0 (N=%d K=%d)", N, K);
     TIC_REQUIRE(TIC_ALIGNED16(A) && TIC_ALIGNED16(B), "gemm_nt: operands must be 16-byte aligned");
     const long tiles_m = (M + 127) / 128;
-    TIC_REQUIRE((double)tiles_m * 128.0 * K * 2.0 < 4294967296.0 && (double)N * K * 2.0 < 4294967296.0,
+    TIC_REQUIRE(((double)tiles_m * 128.0 + 128.0) * K * 2.0 < 4294967296.0 && (double)N * K * 2.0 < 4294967296.0,
                 "gemm_nt: operand exceeds the 4 GiB buffer-resource range");
     GemmNtParams p;
     memset(&p, 0, sizeof(p));
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.bias = bias;
     p.out = (bf16_t*)out_bf16; p.out2 = (bf16_t*)out2_bf16; p.out_f32 = out_f32; p.resid = resid;
     p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches;
-    const int grid = (int)(tiles_m * (N / 128));
+    // big products go to the deep-pipelined 256x256 kernel (one block per CU), the rest to the 128x128 one
+    const bool big = (N % 256 == 0) && (g_opt_gemm_tile == 256 || (g_opt_gemm_tile == 0 && (long)M * N >= (long)2048 * 1024));
+    const int grid = big ? (int)(((M + 255) / 256) * (N / 256)) : (int)(tiles_m * (N / 128));
+#define TIC_GEMM_NT_LAUNCH(E)                                                                        \
+    do {                                                                                             \
+        if (big) {                                                                                   \
+            TIC_RT_MAX_LDS(gemm_nt256_kernel<E>, G256_LDS_BYTES);                                    \
+            TIC_LAUNCH(gemm_nt256_kernel<E>, grid, 512, G256_LDS_BYTES, stream, p);                  \
+        } else {                                                                                     \
+            TIC_RT_MAX_LDS(gemm_nt_kernel<E>, GEMM_LDS_BYTES);                                       \
+            TIC_LAUNCH(gemm_nt_kernel<E>, grid, 256, GEMM_LDS_BYTES, stream, p);                     \
+        }                                                                                            \
+    } while (0)
     switch (epilogue) {
         case TIC_EPI_BF16:
             TIC_REQUIRE(out_bf16, "gemm_nt: EPI_BF16 needs out_bf16");
-            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_BF16>, GEMM_LDS_BYTES);
-            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_BF16>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_BF16);
             break;
         case TIC_EPI_GELU:
             TIC_REQUIRE(out_bf16 && out2_bf16, "gemm_nt: EPI_GELU needs out_bf16 and out2_bf16");
-            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_GELU>, GEMM_LDS_BYTES);
-            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_GELU>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_GELU);
             break;
         case TIC_EPI_RESID:
             TIC_REQUIRE(out_f32 && resid, "gemm_nt: EPI_RESID needs out_f32 and resid");
-            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_RESID>, GEMM_LDS_BYTES);
-            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_RESID>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_RESID);
             break;
         case TIC_EPI_DGELU:
             TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_DGELU needs out_bf16 and aux_bf16");
-            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_DGELU>, GEMM_LDS_BYTES);
-            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_DGELU>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_DGELU);
             break;
         case TIC_EPI_PATCH:
             TIC_REQUIRE(out_f32 && rowtab && patches > 0 && M % patches == 0, "gemm_nt: EPI_PATCH needs out_f32, rowtab, M %% patches == 0");
-            TIC_RT_MAX_LDS(gemm_nt_kernel<TIC_EPI_PATCH>, GEMM_LDS_BYTES);
-            TIC_LAUNCH(gemm_nt_kernel<TIC_EPI_PATCH>, grid, 256, GEMM_LDS_BYTES, stream, p);
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_PATCH);
             break;
         default:
             return tic_fail(TIC_EINVAL, "gemm_nt: unknown epilogue %d", epilogue);
     }
+#undef TIC_GEMM_NT_LAUNCH
     return tic_after_launch("gemm_nt");
 }
 
