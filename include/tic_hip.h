@@ -51,6 +51,10 @@ int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int epil
 /* C[N,K] += A[M,N]^T . B[M,K]  (fp32 accumulate into C; C holds the running gradient).
  * N % 128 == 0, K % 128 == 0.  Replaces the dW half of nn.Linear backward (autograd, finetune.py:62). */
 int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, tic_stream_t stream);
+/* the same for up to 4 problems sharing M (the four Linear layers of a transformer block) in ONE launch of
+ * full-reduction 256x256 tiles (no split-K, no atomics) when shapes allow, else one launch per problem */
+int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N,
+                           const int* K, int M, tic_stream_t stream);
 
 /* LayerNorm(eps) over the last dim of fp32 rows -> bf16; saves mean / rstd.  in_stride = elements
  * between consecutive input rows (D for the token stream, N*D to pick the CLS rows).  HF:261-262,274,281,385. */
@@ -121,7 +125,7 @@ typedef struct {
     /* byte offsets into the activation workspace */
     size_t P, hs, hs_stride, layer_ws, layer_ws_stride;
     size_t a1, mean1, rstd1, qkv, lse, o, hmid, a2, mean2, rstd2, u, g; /* inside a layer_ws block */
-    size_t zf, meanf, rstdf, logits, dlogits, dzf, dh, dhb, du, da, dqkv, dpatch;
+    size_t zf, meanf, rstdf, logits, dlogits, dzf, dh, dhb, dhb2, du, da, dqkv, dpatch;
     size_t ws_bytes;
 } TicVitLayout;
 

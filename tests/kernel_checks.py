@@ -208,3 +208,22 @@ def check_head_and_xent(env, soft):
     torch.testing.assert_close(dz.float(), bfr(dl) @ bfr(W), atol=1e-3, rtol=0.02)
     torch.testing.assert_close(dW, bfr(dl).t() @ z.float(), atol=1e-4, rtol=1e-3)
     torch.testing.assert_close(db, bfr(dl).sum(0), atol=1e-5, rtol=1e-4)
+
+
+def check_gemm_tn_group(env, M, shapes):
+    """grouped dW: C_g += A_g^T B_g for several (N, K) sharing M, accumulate semantics"""
+    import ctypes
+    rnd, call, dev = env.rnd, env.call, env.dev
+    As = [bf(rnd(M, n)) for n, k in shapes]
+    Bs = [bf(rnd(M, k)) for n, k in shapes]
+    Cs = [rnd(n, k) for n, k in shapes]
+    refs = [c + a.float().t() @ b.float() for a, b, c in zip(As, Bs, Cs)]
+    n = len(shapes)
+    PA = (ctypes.c_void_p * n)(*[ptr(a) for a in As])
+    PB = (ctypes.c_void_p * n)(*[ptr(b) for b in Bs])
+    PC = (ctypes.c_void_p * n)(*[ptr(c) for c in Cs])
+    NN = (ctypes.c_int * n)(*[s_[0] for s_ in shapes])
+    KK = (ctypes.c_int * n)(*[s_[1] for s_ in shapes])
+    call("tic_gemm_tn_group_bf16", n, PA, PB, PC, NN, KK, M, None)
+    for c, r in zip(Cs, refs):
+        torch.testing.assert_close(c, r, atol=2e-3 * max(1.0, (M / 200) ** 0.5), rtol=1e-3)

@@ -76,3 +76,15 @@ def test_gemm_nt256_pipelined(env, M, N, K):
             assert torch.equal(ops.gemm_nt(a, w, ops.EPI_BF16, bias=bias), ref)
     finally:
         call("tic_set_option", b"gemm_tile", 0)
+
+
+@pytest.mark.parametrize("M,shapes", [(200, [(256, 256)]), (12608, [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 1024)]),
+                                      (1970, [(768, 3072), (3072, 768), (768, 768), (2304, 768)])])
+def test_gemm_tn_group(env, M, shapes):
+    kc.check_gemm_tn_group(env, M, shapes)
+    from touhouimageclassification_amd._lib import call
+    call("tic_set_option", b"gemm_tile", 256)
+    try:
+        kc.check_gemm_tn_group(env, M, shapes)
+    finally:
+        call("tic_set_option", b"gemm_tile", 0)

@@ -67,3 +67,12 @@ def test_gemm_nt256_pipelined(env, M, N, K):
             kc.check_gemm_nt_gelu_resid_dgelu_patch(env, N=256, K=192, imgs=3, Pn=50)
     finally:
         call("tic_set_option", b"gemm_tile", 0)
+
+
+@pytest.mark.parametrize("M,shapes", [(200, [(256, 256)]), (333, [(256, 512), (512, 256), (256, 256)]), (64, [(128, 256), (256, 256)])])
+def test_gemm_tn_group(env, M, shapes):
+    call("tic_set_option", b"gemm_tile", 256)
+    try:
+        kc.check_gemm_tn_group(env, M, shapes)   # last case has a 128-multiple shape -> per-problem fallback
+    finally:
+        call("tic_set_option", b"gemm_tile", 0)

@@ -76,6 +76,27 @@ def main():
             c = torch.zeros(n, k, device=dev)
             ms = time_ms(lambda: call("tic_gemm_tn_bf16", a.data_ptr(), x.data_ptr(), c.data_ptr(), M, n, k, current_stream()))
             print(f"B={B:4d} {name:12s} M={M:6d} N={n:5d} K={k:5d}  TN: {2.0 * M * n * k / ms / 1e9:7.1f} TF", flush=True)
+        tn_group(M, D, F, dev)
+
+
+def tn_group(M, D, F, dev):
+    import ctypes
+    shapes = [(D, F), (F, D), (D, D), (3 * D, D)]
+    As = [torch.randn(M, n, device=dev).to(torch.bfloat16) for n, k in shapes]
+    Bs = [torch.randn(M, k, device=dev).to(torch.bfloat16) for n, k in shapes]
+    Cs = [torch.zeros(n, k, device=dev) for n, k in shapes]
+    n = 4
+    PA = (ctypes.c_void_p * n)(*[a.data_ptr() for a in As])
+    PB = (ctypes.c_void_p * n)(*[b.data_ptr() for b in Bs])
+    PC = (ctypes.c_void_p * n)(*[c.data_ptr() for c in Cs])
+    NN = (ctypes.c_int * n)(*[s_[0] for s_ in shapes])
+    KK = (ctypes.c_int * n)(*[s_[1] for s_ in shapes])
+    fl = sum(2.0 * M * a * b for a, b in shapes)
+    for tile in (128, 256, 128, 256):
+        call("tic_set_option", b"gemm_tile", tile)
+        ms = time_ms(lambda: call("tic_gemm_tn_group_bf16", n, PA, PB, PC, NN, KK, M, current_stream()))
+        print(f"M={M} dW group of 4 (tile {tile}): {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF", flush=True)
+    call("tic_set_option", b"gemm_tile", 0)
 
 
 if __name__ == "__main__":

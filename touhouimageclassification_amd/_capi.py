@@ -29,7 +29,7 @@ class TicVitLayout(C.Structure):
         "t_layer_stride", "t_wqkv", "t_wo", "t_w1", "t_w2", "t_total")] + [(n, SZ) for n in (
         "P", "hs", "hs_stride", "layer_ws", "layer_ws_stride",
         "a1", "mean1", "rstd1", "qkv", "lse", "o", "hmid", "a2", "mean2", "rstd2", "u", "g",
-        "zf", "meanf", "rstdf", "logits", "dlogits", "dzf", "dh", "dhb", "du", "da", "dqkv", "dpatch",
+        "zf", "meanf", "rstdf", "logits", "dlogits", "dzf", "dh", "dhb", "dhb2", "du", "da", "dqkv", "dpatch",
         "ws_bytes")]
 
 
@@ -43,6 +43,7 @@ SIGNATURES = {
     "tic_set_option": ([C.c_char_p, I], I),
     "tic_gemm_nt_bf16": ([P, P, I, I, I, I, P, P, P, P, P, P, P, I, P], I),
     "tic_gemm_tn_bf16": ([P, P, P, I, I, I, P], I),
+    "tic_gemm_tn_group_bf16": ([I, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I), I, P], I),
     "tic_layernorm_fwd": ([P, L, P, P, P, P, P, I, I, F, P], I),
     "tic_layernorm_bwd": ([P, P, L, P, P, P, P, P, P, P, P, I, I, P], I),
     "tic_attention_fwd": ([P, P, P, I, I, I, F, P], I),

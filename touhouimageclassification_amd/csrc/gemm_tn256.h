@@ -1,0 +1,196 @@
+// gemm_tn256.h -- grouped, deep-pipelined weight-gradient GEMM (gfx950).
+//
+//   for each problem g of a group (the four Linear layers of one transformer block):
+//       C_g[N_g, K_g] += A_g[M, N_g]^T . B_g[M, K_g]          (dW = dY^T . X, fp32)
+//
+// One launch covers the whole group: 256x256 output tiles, ONE workgroup (8 waves) per tile running the
+// full reduction over M, so there is no split-K, no atomics and no reduction pass; a ViT-L block gives
+// 48 + 16 + 64 + 64 = 192 tiles for 256 CUs.  Same 4-phase / counted-vmcnt / staggered-wave-group
+// pipeline as gemm256.h (see the hazard bookkeeping there); what differs is the operand geometry:
+// both operands are reduction-major in memory ([m][n] and [m][k]), so the LDS half-tiles are
+// [64 m][128 columns] (256-B rows, swz256) and every fragment comes from ds_read_b64_tr_b16 feeding
+// v_mfma_f32_32x32x16_bf16 in its natural orientation (D column = k = contiguous in C: each store
+// instruction writes two full 128-B row segments).
+#pragma once
+#include "gemm256.h"
+
+#define TN_MAX_GROUP 4
+struct GemmTnProblem {
+    const bf16_t* A;   // [M, N]
+    const bf16_t* B;   // [M, K]
+    float* C;          // [N, K]
+    int N, K;
+    int tile_start;    // first tile index of this problem inside the launch
+};
+struct GemmTnGroupParams {
+    GemmTnProblem prob[TN_MAX_GROUP];
+    int nprob, M, total_tiles;
+};
+
+__global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp) {
+    const int tid = TIC_TID, l = tid & 63, w = wave_id();
+    const int wr = w >> 2, wc = w & 3;
+    // XCD-contiguous tile order, then problem lookup (wave-uniform)
+    int wg;
+    {
+        const int bid = TIC_BID_X, nwg = gp.total_tiles;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    int pi = 0;
+#pragma unroll
+    for (int g = 1; g < TN_MAX_GROUP; ++g)
+        if (g < gp.nprob && wg >= gp.prob[g].tile_start) pi = g;
+    const bf16_t* Ap = gp.prob[0].A;
+    const bf16_t* Bp = gp.prob[0].B;
+    float* Cp = gp.prob[0].C;
+    int N = gp.prob[0].N, K = gp.prob[0].K, t0 = 0;
+#pragma unroll
+    for (int g = 1; g < TN_MAX_GROUP; ++g)
+        if (pi == g) {
+            Ap = gp.prob[g].A; Bp = gp.prob[g].B; Cp = gp.prob[g].C; N = gp.prob[g].N; K = gp.prob[g].K; t0 = gp.prob[g].tile_start;
+        }
+    const int tiles_k = K / 256, lt = wg - t0;
+    const int n0 = (lt / tiles_k) * 256, k0 = (lt % tiles_k) * 256;
+    const int M = gp.M;
+    const tic_rsrc_t ra = make_rsrc(Ap, (uint32_t)((size_t)M * N * 2));
+    const tic_rsrc_t rb = make_rsrc(Bp, (uint32_t)((size_t)M * K * 2));
+
+    // ---- LDS-DMA: half-tile = [64 m][128 cols] = 16 pieces of 4 rows; this wave moves pieces 2w, 2w+1.
+    // The row advance lives in the VGPR offset (only that offset is range-checked: rows >= M read 0).
+    const uint32_t rr = (uint32_t)l >> 4, ch_log = ((uint32_t)l & 15u) ^ (rr << 2);
+    uint32_t voa[2][2], vob[2][2];   // [half][piece], running
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t row = (uint32_t)(2 * w + j) * 4 + rr;
+            voa[h][j] = (uint32_t)(((size_t)row * N + n0 + h * 128 + ch_log * 8) * 2);
+            vob[h][j] = (uint32_t)(((size_t)row * K + k0 + h * 128 + ch_log * 8) * 2);
+        }
+    const uint32_t stepA = (uint32_t)N * 128u, stepB = (uint32_t)K * 128u;   // 64 rows in bytes
+    // which: 0 = A0, 1 = B0, 2 = B1, 3 = A1 ; each call also advances that half-tile's offsets to the next step
+    auto issue = [&](int buf, int which) {
+        const bool isA = (which == 0 || which == 3);
+        const int h = (which >= 2) ? 1 : 0;
+        const uint32_t base = (uint32_t)buf * G256_BUF_BYTES + (isA ? 0u : 32768u) + (uint32_t)h * 16384u + (uint32_t)(2 * w) * 1024u;
+        if (isA) {
+            glds16(ra, base, voa[h][0], 0);
+            glds16(ra, base + 1024u, voa[h][1], 0);
+            voa[h][0] += stepA;
+            voa[h][1] += stepA;
+        } else {
+            glds16(rb, base, vob[h][0], 0);
+            glds16(rb, base + 1024u, vob[h][1], 0);
+            vob[h][0] += stepB;
+            vob[h][1] += stepB;
+        }
+    };
+
+    // ---- transposed fragments (32x32x16): lane (h2 = l>>5, c16 = (l>>4)&1, q = (l>>2)&3, p4 = l&3)
+    const uint32_t h2 = (uint32_t)l >> 5, c16 = ((uint32_t)l >> 4) & 1u, q4 = ((uint32_t)l >> 2) & 3u, p4 = (uint32_t)l & 3u;
+    auto tr_frag = [&](uint32_t half_base, uint32_t col0, uint32_t ks) -> bf16x8 {
+        const uint32_t col = col0 + 16 * c16 + 4 * p4;
+        const uint32_t row = 16 * ks + 8 * h2 + q4;             // row & 3 == q4 for both reads
+        const uint32_t inrow = (((col >> 3) ^ (q4 << 2)) * 16u) + (col & 4u) * 2u;
+        const bf16x4 lo = lds_tr64(half_base + row * 256u + inrow);
+        const bf16x4 hi = lds_tr64(half_base + (row + 4u) * 256u + inrow);
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    f32x16 acc[2][2][2];   // [i][j][nt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][nt][r] = 0.f;
+    bf16x8 fa[2][4], fb[4];   // [nt][ks], [ks]
+
+    auto load_a = [&](uint32_t bufb, int i) {
+#pragma unroll
+        for (uint32_t nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (uint32_t ks = 0; ks < 4; ++ks) fa[nt][ks] = tr_frag(bufb + (uint32_t)i * 16384u, (uint32_t)wr * 64 + nt * 32, ks);
+    };
+    auto load_b = [&](uint32_t bufb, int j) {
+#pragma unroll
+        for (uint32_t ks = 0; ks < 4; ++ks) fb[ks] = tr_frag(bufb + 32768u + (uint32_t)j * 16384u, (uint32_t)wc * 32, ks);
+    };
+    auto mma = [&](int i, int j) {
+        prio_hi();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[i][j][nt] = mfma32(fa[nt][ks], fb[ks], acc[i][j][nt]);
+        prio_lo();
+    };
+
+    const int nsteps = (M + 63) / 64;
+    issue(0, 0);
+    issue(0, 1);
+    issue(0, 2);
+    issue(0, 3);
+    wait_vmcnt0();
+    g256_barrier();
+    if (wr == 1) g256_barrier();
+
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES;
+        const bool more = (st + 1 < nsteps);
+        load_a(bufb, 0);
+        load_b(bufb, 0);
+        if (more) {
+            issue(cur ^ 1, 0);
+            wait_vmcnt<4>();
+        } else {
+            wait_vmcnt<2>();
+        }
+        g256_barrier();
+        mma(0, 0);
+        g256_barrier();
+        load_b(bufb, 1);
+        if (more) {
+            issue(cur ^ 1, 1);
+            wait_vmcnt<4>();
+        } else {
+            wait_vmcnt0();
+        }
+        g256_barrier();
+        mma(0, 1);
+        g256_barrier();
+        load_a(bufb, 1);
+        if (more) issue(cur ^ 1, 2);
+        g256_barrier();
+        mma(1, 1);
+        g256_barrier();
+        load_b(bufb, 0);
+        if (more) {
+            issue(cur ^ 1, 3);
+            wait_vmcnt<4>();
+        }
+        g256_barrier();
+        mma(1, 0);
+        g256_barrier();
+    }
+    if (wr == 0) g256_barrier();
+
+    // C += acc : D column = l&31 -> k (contiguous), row = (r&3) + 8(r>>2) + 4(l>>5) -> n
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int kk = k0 + j * 128 + wc * 32 + (l & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + i * 128 + wr * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                    float* dst = Cp + (size_t)n * K + kk;
+                    *dst = *dst + acc[i][j][nt][r];
+                }
+            }
+}

@@ -12,6 +12,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "gemm256.h"
+#include "gemm_tn256.h"
 #include "norm.h"
 
 static thread_local char g_tic_err[512] = "";
@@ -27,6 +28,11 @@ static int tic_fail(int code, const char* fmt, ...) {
         if (!(cond)) return tic_fail(TIC_EINVAL, __VA_ARGS__); \
     } while (0)
 #define TIC_ALIGNED16(p) ((((uintptr_t)(p)) & 15u) == 0)
+#define TIC_TRY(call)            \
+    do {                         \
+        const int rc_ = (call);  \
+        if (rc_ != TIC_OK) return rc_; \
+    } while (0)
 
 static int tic_after_launch(const char* what) {
     const char* e = TIC_RT_LAST_ERROR();
@@ -122,6 +128,38 @@ extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, i
     TIC_RT_MAX_LDS(gemm_tn_kernel, GEMM_LDS_BYTES);
     TIC_LAUNCH(gemm_tn_kernel, dim3(tiles, split), 256, GEMM_LDS_BYTES, stream, p);
     return tic_after_launch("gemm_tn");
+}
+
+// grouped dW: one launch of 256x256 full-M tiles when every problem allows it and there are enough tiles to
+// occupy the chip; otherwise one split-M launch per problem
+extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N,
+                                      const int* K, int M, tic_stream_t stream) {
+    TIC_REQUIRE(nprob >= 1 && nprob <= TN_MAX_GROUP && A && B && C && N && K && M >= 1, "gemm_tn_group: bad argument (nprob=%d)", nprob);
+    bool ok256 = true;
+    int tiles = 0;
+    for (int g = 0; g < nprob; ++g) {
+        TIC_REQUIRE(A[g] && B[g] && C[g] && TIC_ALIGNED16(A[g]) && TIC_ALIGNED16(B[g]), "gemm_tn_group: null / misaligned operand %d", g);
+        TIC_REQUIRE(N[g] % 128 == 0 && K[g] % 128 == 0 && N[g] >= 128 && K[g] >= 128, "gemm_tn_group: need N, K multiples of 128 (problem %d: N=%d K=%d)", g, N[g], K[g]);
+        TIC_REQUIRE(((double)M + 64.0) * (N[g] > K[g] ? N[g] : K[g]) * 2.0 < 4294967296.0, "gemm_tn_group: operand exceeds the 4 GiB buffer-resource range");
+        if (N[g] % 256 || K[g] % 256) ok256 = false;
+        tiles += (N[g] / 256) * (K[g] / 256);
+    }
+    if (ok256 && g_opt_gemm_tile != 128 && (g_opt_gemm_tile == 256 || (tiles >= 96 && M >= 2048))) {
+        GemmTnGroupParams gp;
+        memset(&gp, 0, sizeof(gp));
+        int t = 0;
+        for (int g = 0; g < nprob; ++g) {
+            gp.prob[g].A = (const bf16_t*)A[g]; gp.prob[g].B = (const bf16_t*)B[g]; gp.prob[g].C = C[g];
+            gp.prob[g].N = N[g]; gp.prob[g].K = K[g]; gp.prob[g].tile_start = t;
+            t += (N[g] / 256) * (K[g] / 256);
+        }
+        gp.nprob = nprob; gp.M = M; gp.total_tiles = t;
+        TIC_RT_MAX_LDS(gemm_tn256_kernel, G256_LDS_BYTES);
+        TIC_LAUNCH(gemm_tn256_kernel, t, 512, G256_LDS_BYTES, stream, gp);
+        return tic_after_launch("gemm_tn_group");
+    }
+    for (int g = 0; g < nprob; ++g) TIC_TRY(tic_gemm_tn_bf16(A[g], B[g], C[g], M, N[g], K[g], stream));
+    return TIC_OK;
 }
 
 // ---- LayerNorm -------------------------------------------------------------------------------------
@@ -334,6 +372,7 @@ extern "C" int tic_vit_layout(const TicVitDims* d, TicVitLayout* o) {
     o->dzf = w; w += pad256(B * D * 2);
     o->dh = w; w += pad256(M * D * 4);
     o->dhb = w; w += pad256(M * D * 2);
+    o->dhb2 = w; w += pad256(M * D * 2);
     o->du = w; w += pad256(M * F * 2);
     o->da = w; w += pad256(M * D * 2);
     o->dqkv = w; w += pad256(M * 3 * D * 2);
@@ -342,11 +381,6 @@ extern "C" int tic_vit_layout(const TicVitDims* d, TicVitLayout* o) {
     return TIC_OK;
 }
 
-#define TIC_TRY(call)            \
-    do {                         \
-        const int rc_ = (call);  \
-        if (rc_ != TIC_OK) return rc_; \
-    } while (0)
 
 struct VitCtx {
     TicVitLayout lay;
@@ -454,22 +488,25 @@ extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stre
     char* du = c.ws + y.du;
     char* da = c.ws + y.da;
     char* dqkv = c.ws + y.dqkv;
-    // MLP
+    char* dhb2 = c.ws + y.dhb2;
+    // dX chain first (MLP, then attention); the four weight gradients of the block go out as ONE grouped launch
     TIC_TRY(tic_gemm_nt_bf16(dhb, lt + y.t_w2, M, F, D, TIC_EPI_DGELU, nullptr, du, nullptr, nullptr, nullptr, a + y.u, nullptr, 0, s));
-    TIC_TRY(tic_gemm_tn_bf16(dhb, a + y.g, lg + y.w2, M, D, F, s));
-    TIC_TRY(tic_colsum_bf16(dhb, lg + y.b2, M, D, s));
     TIC_TRY(tic_gemm_nt_bf16(du, lt + y.t_w1, M, D, F, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
-    TIC_TRY(tic_gemm_tn_bf16(du, a + y.a2, lg + y.w1, M, F, D, s));
-    TIC_TRY(tic_colsum_bf16(du, lg + y.b1, M, F, s));
-    TIC_TRY(tic_layernorm_bwd(da, (float*)(a + y.hmid), D, lp + y.ln2_g, (float*)(a + y.mean2), (float*)(a + y.rstd2), dh, dh, dhb, lg + y.ln2_g,
+    TIC_TRY(tic_layernorm_bwd(da, (float*)(a + y.hmid), D, lp + y.ln2_g, (float*)(a + y.mean2), (float*)(a + y.rstd2), dh, dh, dhb2, lg + y.ln2_g,
                               lg + y.ln2_b, M, D, s));
-    // attention
-    TIC_TRY(tic_gemm_nt_bf16(dhb, lt + y.t_wo, M, D, D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
-    TIC_TRY(tic_gemm_tn_bf16(dhb, a + y.o, lg + y.wo, M, D, D, s));
-    TIC_TRY(tic_colsum_bf16(dhb, lg + y.bo, M, D, s));
+    TIC_TRY(tic_gemm_nt_bf16(dhb2, lt + y.t_wo, M, D, D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
     TIC_TRY(tic_attention_bwd(a + y.qkv, a + y.o, (float*)(a + y.lse), da, dqkv, B, (int)c.H, N, 0.125f, s));
     TIC_TRY(tic_gemm_nt_bf16(dqkv, lt + y.t_wqkv, M, D, 3 * D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
-    TIC_TRY(tic_gemm_tn_bf16(dqkv, a + y.a1, lg + y.wqkv, M, 3 * D, D, s));
+    {
+        const void* gA[4] = {dhb, du, dhb2, dqkv};
+        const void* gB[4] = {a + y.g, a + y.a2, a + y.o, a + y.a1};
+        float* gC[4] = {lg + y.w2, lg + y.w1, lg + y.wo, lg + y.wqkv};
+        const int gN[4] = {D, F, D, 3 * D}, gK[4] = {F, D, D, D};
+        TIC_TRY(tic_gemm_tn_group_bf16(4, gA, gB, gC, gN, gK, M, s));
+    }
+    TIC_TRY(tic_colsum_bf16(dhb, lg + y.b2, M, D, s));
+    TIC_TRY(tic_colsum_bf16(du, lg + y.b1, M, F, s));
+    TIC_TRY(tic_colsum_bf16(dhb2, lg + y.bo, M, D, s));
     TIC_TRY(tic_colsum_bf16(dqkv, lg + y.bqkv, M, 3 * D, s));
     TIC_TRY(tic_layernorm_bwd(da, hin, D, lp + y.ln1_g, (float*)(a + y.mean1), (float*)(a + y.rstd1), dh, dh, dhb, lg + y.ln1_g, lg + y.ln1_b, M, D, s));
     return TIC_OK;
