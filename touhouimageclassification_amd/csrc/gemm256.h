@@ -27,6 +27,9 @@
 #define G256_BUF_BYTES 65536u   // A 32 KiB + B 32 KiB
 #define G256_LDS_BYTES (2u * G256_BUF_BYTES)
 
+struct TrueTag { static constexpr bool value = true; };
+struct FalseTag { static constexpr bool value = false; };
+
 TIC_DEV void g256_barrier() {
 #ifndef TIC_SIM
     asm volatile("" ::: "memory");
@@ -125,14 +128,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     g256_barrier();
     if (wr == 1) g256_barrier();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K tile; MORE = a next tile exists (its half-tiles are issued here).  The steady-state body is
+    // branch-free so the accumulators stay in place across the back-edge (no register copies).
+    auto ktile = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
         const int cur = kt & 1;
         const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES;
-        const bool more = (kt + 1 < nk);
         // ---- phase 0: Q00 needs A0, B0 (landed: waited for in phase 3 of the previous tile / prologue)
         load_a(bufb, 0);
         load_b(bufb, 0);
-        if (more) {
+        if constexpr (MORE) {
             issue(cur ^ 1, kt + 1, 0);
             wait_vmcnt<4>();   // B1 of THIS tile has landed (A1 + the new A0 stay in flight)
         } else {
@@ -143,7 +148,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         g256_barrier();
         // ---- phase 1: Q01 needs B1
         load_b(bufb, 1);
-        if (more) {
+        if constexpr (MORE) {
             issue(cur ^ 1, kt + 1, 1);
             wait_vmcnt<4>();   // A1 of THIS tile has landed
         } else {
@@ -154,20 +159,23 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         g256_barrier();
         // ---- phase 2: Q11 needs A1
         load_a(bufb, 1);
-        if (more) issue(cur ^ 1, kt + 1, 2);
+        if constexpr (MORE) issue(cur ^ 1, kt + 1, 2);
         g256_barrier();
         mma(1, 1);
         g256_barrier();
         // ---- phase 3: Q10 needs B0 again
         load_b(bufb, 0);
-        if (more) {
+        if constexpr (MORE) {
             issue(cur ^ 1, kt + 1, 3);
             wait_vmcnt<4>();   // A0, B0 of the NEXT tile have landed (B1, A1 in flight)
         }
         g256_barrier();
         mma(1, 0);
         g256_barrier();
-    }
+    };
+#pragma nounroll
+    for (int kt = 0; kt + 1 < nk; ++kt) ktile(kt, TrueTag{});
+    ktile(nk - 1, FalseTag{});
     if (wr == 0) g256_barrier();   // re-balance the stagger
 
 #pragma unroll

@@ -137,13 +137,15 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
     g256_barrier();
     if (wr == 1) g256_barrier();
 
-    for (int st = 0; st < nsteps; ++st) {
+    // one K tile; MORE = a next tile exists (its half-tiles are issued here).  The steady-state body is
+    // branch-free so the accumulators stay in place across the back-edge (no register copies).
+    auto ktile = [&](int st, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
         const int cur = st & 1;
         const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES;
-        const bool more = (st + 1 < nsteps);
         load_a(bufb, 0);
         load_b(bufb, 0);
-        if (more) {
+        if constexpr (MORE) {
             issue(cur ^ 1, 0);
             wait_vmcnt<4>();
         } else {
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
         mma(0, 0);
         g256_barrier();
         load_b(bufb, 1);
-        if (more) {
+        if constexpr (MORE) {
             issue(cur ^ 1, 1);
             wait_vmcnt<4>();
         } else {
@@ -163,19 +165,22 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
         mma(0, 1);
         g256_barrier();
         load_a(bufb, 1);
-        if (more) issue(cur ^ 1, 2);
+        if constexpr (MORE) issue(cur ^ 1, 2);
         g256_barrier();
         mma(1, 1);
         g256_barrier();
         load_b(bufb, 0);
-        if (more) {
+        if constexpr (MORE) {
             issue(cur ^ 1, 3);
             wait_vmcnt<4>();
         }
         g256_barrier();
         mma(1, 0);
         g256_barrier();
-    }
+    };
+#pragma nounroll
+    for (int st = 0; st + 1 < nsteps; ++st) ktile(st, TrueTag{});
+    ktile(nsteps - 1, FalseTag{});
     if (wr == 0) g256_barrier();
 
     // C += acc : D column = l&31 -> k (contiguous), row = (r&3) + 8(r>>2) + 4(l>>5) -> n
