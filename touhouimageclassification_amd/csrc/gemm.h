@@ -50,13 +50,31 @@ TIC_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& tm, in
     tn = in_group / gsize;
 }
 
-// one lane's 4 consecutive outputs (row m, columns n..n+3) of any epilogue
+// ---- epilogue ---------------------------------------------------------------------------------------
+// A lane owns, per output row m, NG groups of 4 consecutive columns.  Bias is loaded ONCE per column group
+// into registers before any store (a load placed after a store to possibly-aliasing memory costs a full
+// vmcnt(0) round trip each time); the per-element extra operand (residual / pre-activation / position
+// row) is fetched one row AHEAD of its use, so the loads of row r+1 fly while row r is computed and stored.
+struct EpiExtra {
+    f32x4 f;   // RESID: residual, PATCH: position-embedding row
+    u32x2 u;   // DGELU: 4 bf16 pre-activations
+};
 template <int EPI>
-TIC_DEV void gemm_epilogue_store(const GemmNtParams& p, int m, int n, f32x4 v) {
-    if (EPI != TIC_EPI_DGELU && p.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-        v += b;
+TIC_DEV EpiExtra epi_fetch(const GemmNtParams& p, int m, int n) {
+    EpiExtra e;
+    e.f = f32x4{0.f, 0.f, 0.f, 0.f};
+    e.u = u32x2{0u, 0u};
+    if (m < p.M) {
+        if (EPI == TIC_EPI_RESID) e.f = *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.N + n);
+        if (EPI == TIC_EPI_DGELU) e.u = *reinterpret_cast<const u32x2*>(p.aux + (size_t)m * p.N + n);
+        if (EPI == TIC_EPI_PATCH) e.f = *reinterpret_cast<const f32x4*>(p.rowtab + (size_t)(1 + m % p.patches) * p.N + n);
     }
+    return e;
+}
+template <int EPI>
+TIC_DEV void epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias, EpiExtra e) {
+    if (m >= p.M) return;
+    if (EPI != TIC_EPI_DGELU) v += bias;
     const size_t o = (size_t)m * p.N + n;
     if (EPI == TIC_EPI_BF16) {
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
@@ -70,26 +88,46 @@ TIC_DEV void gemm_epilogue_store(const GemmNtParams& p, int m, int n, f32x4 v) {
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(u[0], u[1]), pack2bf(u[2], u[3])};
         *reinterpret_cast<u32x2*>(p.out2 + o) = u32x2{pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
     } else if (EPI == TIC_EPI_RESID) {
-        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + o);
         f32x4 y;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = rs[r] + bfround(v[r]);
+        for (int r = 0; r < 4; ++r) y[r] = e.f[r] + bfround(v[r]);
         *reinterpret_cast<f32x4*>(p.out_f32 + o) = y;
     } else if (EPI == TIC_EPI_DGELU) {
-        const u32x2 ur = *reinterpret_cast<const u32x2*>(p.aux + o);
-        const float u0 = bf2f((bf16_t)(ur[0] & 0xffff)), u1 = bf2f((bf16_t)(ur[0] >> 16));
-        const float u2 = bf2f((bf16_t)(ur[1] & 0xffff)), u3 = bf2f((bf16_t)(ur[1] >> 16));
+        const float u0 = bf2f((bf16_t)(e.u[0] & 0xffff)), u1 = bf2f((bf16_t)(e.u[0] >> 16));
+        const float u2 = bf2f((bf16_t)(e.u[1] & 0xffff)), u3 = bf2f((bf16_t)(e.u[1] >> 16));
         const float d0 = bfround(v[0]) * gelu_erf_grad(u0), d1 = bfround(v[1]) * gelu_erf_grad(u1);
         const float d2 = bfround(v[2]) * gelu_erf_grad(u2), d3 = bfround(v[3]) * gelu_erf_grad(u3);
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
     } else if (EPI == TIC_EPI_PATCH) {
         const int img = m / p.patches, pi = m - img * p.patches;
         const size_t orow = (size_t)img * (p.patches + 1) + 1 + pi;
-        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.rowtab + (size_t)(1 + pi) * p.N + n);
         f32x4 y;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = bfround(v[r]) + pe[r];
+        for (int r = 0; r < 4; ++r) y[r] = bfround(v[r]) + e.f[r];
         *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.N + n) = y;
+    }
+}
+// NR rows x NG column groups per lane; row_of(r) / col_of(g) give the global coordinates, acc_of(r, g) the value
+template <int EPI, int NR, int NG, class RowF, class ColF, class AccF>
+TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF acc_of) {
+    f32x4 bias[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+        bias[g] = (EPI != TIC_EPI_DGELU && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + col_of(g)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_PATCH);
+    EpiExtra ex[2][NG];
+    if (HAS_EXTRA) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ex[0][g] = epi_fetch<EPI>(p, row_of(0), col_of(g));
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (HAS_EXTRA && r + 1 < NR) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) ex[(r + 1) & 1][g] = epi_fetch<EPI>(p, row_of(r + 1), col_of(g));
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) epi_store<EPI>(p, row_of(r), col_of(g), acc_of(r, g), bias[g], ex[r & 1][g]);
     }
 }
 
@@ -173,13 +211,9 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
     }
 
     // ---- epilogue: lane holds rows m = ..+(l&15), 4 consecutive n = ..+4(l>>4) ------------------------
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + (l & 15);
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) gemm_epilogue_store<EPI>(p, m, n0 + wn * 64 + nt * 16 + 4 * (l >> 4), acc[mt][nt]);
-    }
+    gemm_epilogue<EPI, 4, 4>(
+        p, [&](int r) { return m0 + wm * 64 + r * 16 + (l & 15); }, [&](int g) { return n0 + wn * 64 + g * 16 + 4 * (l >> 4); },
+        [&](int r, int g) { return acc[r][g]; });
 }
 
 // ------------------------------------------------------------------------------------------------------

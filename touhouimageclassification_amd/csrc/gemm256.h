@@ -178,16 +178,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     ktile(nk - 1, FalseTag{});
     if (wr == 0) g256_barrier();   // re-balance the stagger
 
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + i * 128 + wr * 64 + mt * 16 + (l & 15);
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    gemm_epilogue_store<EPI>(p, m, n0 + j * 128 + wc * 32 + nt * 16 + 4 * (l >> 4), acc[i][j][mt][nt]);
-        }
+    // rows r = i*4 + mt, column groups g = j*2 + nt
+    gemm_epilogue<EPI, 8, 4>(
+        p, [&](int r) { return m0 + (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (l & 15); },
+        [&](int g) { return n0 + (g >> 1) * 128 + wc * 32 + (g & 1) * 16 + 4 * (l >> 4); },
+        [&](int r, int g) { return acc[r >> 2][g >> 1][r & 3][g & 1]; });
 }
