@@ -14,13 +14,20 @@
 //     s_barrier
 // The two wave groups (wr = 0 / 1 -- the two waves that share each SIMD) run ONE barrier apart, so one
 // group's MFMA segment overlaps the other's load segment (matrix beside memory on every SIMD).
-// LDS-DMA stays in flight across barriers (raw s_barrier, never __syncthreads); vmcnt(4) leaves two
-// half-tiles in flight.  Hazard bookkeeping (interval = time between consecutive barriers; group 0 runs
-// its load segment of global phase P in interval 2P, group 1 in 2P+1):
-//   RAW  a half-tile read first in phase P is waited for (by every wave that issued a piece of it) in
-//        the load segment of phase P-1, i.e. no later than interval 2P-1, and read from interval 2P on;
-//   WAR  a half-tile slot is re-filled >= 2 phases after the last ds_read of it (B0: read in phase 3 of
-//        tile t-1, re-filled in phase 1 of tile t; the others are further apart).
+// LDS-DMA stays in flight across barriers (raw s_barrier, never __syncthreads).  Prefetch is 5-6 phases
+// deep inside the two K-tile buffers: the B0 fragments stay in registers for the whole tile, so every
+// half-tile slot is read in exactly one phase and is re-filled as soon as that read has retired:
+//     tile t phase 0: issue B1(t+1)   phase 1: A1(t+1)   phase 2: A0(t+2)   phase 3: B0(t+2)
+// i.e. A0/B0 of tile t+2 go into the buffer tile t is still being computed from.  vmcnt(8) at phases
+// 3, 0, 1 leaves four half-tiles (64 KiB per CU) in flight.  K tiles past the end are issued with an
+// out-of-range offset (the hardware range check turns them into zero fills with no memory traffic) so
+// the steady-state body and its vmcnt counts are the same for every tile.
+// Hazard bookkeeping (interval = time between consecutive barriers; group 0 runs its load segment of
+// global phase P in interval 2P, group 1 in 2P+1):
+//   RAW  a half-tile read in phase P is waited for (by every wave that issued a piece of it) in the load
+//        segment of phase P-1, i.e. no later than interval 2P-1, and read from interval 2P on;
+//   WAR  a slot is re-filled >= 2 phases after its only read (A0: read ph 0 -> filled ph 2; B0: ph 0 -> ph 3;
+//        B1: ph 1 -> next ph 0; A1: ph 2 -> next ph 1).
 #pragma once
 #include "gemm.h"
 
@@ -62,18 +69,20 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
             voa[h][j] = (uint32_t)(((size_t)(m0 + r) * p.K + slot_log * 8) * 2);
             vob[h][j] = (uint32_t)(((size_t)(n0 + r) * p.K + slot_log * 8) * 2);
         }
-    // which: 0 = A0, 1 = B0, 2 = B1, 3 = A1 (issue order inside a K tile)
+    // which: 0 = A0, 1 = B0, 2 = B1, 3 = A1.  K tiles >= nk become zero fills (see header).
+    const int nk = p.K / 64;
     auto issue = [&](int buf, int kt, int which) {
         const uint32_t soff = (uint32_t)kt * 128u;
         const bool isA = (which == 0 || which == 3);
         const int h = (which >= 2) ? 1 : 0;
+        const bool live = kt < nk;
         const uint32_t base = (uint32_t)buf * G256_BUF_BYTES + (isA ? 0u : 32768u) + (uint32_t)h * 16384u + (uint32_t)(2 * w) * 1024u;
         if (isA) {
-            glds16(ra, base, voa[h][0], soff);
-            glds16(ra, base + 1024u, voa[h][1], soff);
+            glds16(ra, base, live ? voa[h][0] : 0xFFFFFFF0u, live ? soff : 0u);
+            glds16(ra, base + 1024u, live ? voa[h][1] : 0xFFFFFFF0u, live ? soff : 0u);
         } else {
-            glds16(rb, base, vob[h][0], soff);
-            glds16(rb, base + 1024u, vob[h][1], soff);
+            glds16(rb, base, live ? vob[h][0] : 0xFFFFFFF0u, live ? soff : 0u);
+            glds16(rb, base + 1024u, live ? vob[h][1] : 0xFFFFFFF0u, live ? soff : 0u);
         }
     };
 
@@ -93,7 +102,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[4][2], fb[2][2];   // [mt][ks], [nt][ks]
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];   // [mt][ks], [nt][ks]; B0 fragments live for the whole K tile
 
     auto load_a = [&](uint32_t bufb, int i) {
 #pragma unroll
@@ -101,13 +110,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = lds_ld128(bufb + ((uint32_t)i * 128 + a_row0 + (uint32_t)mt * 16) * 128u + fo[ks]);
     };
-    auto load_b = [&](uint32_t bufb, int j) {
+    auto load_b = [&](uint32_t bufb, int j, bf16x8 (&fb)[2][2]) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fb[nt][ks] = lds_ld128(bufb + 32768u + ((uint32_t)j * 128 + b_row0 + (uint32_t)nt * 16) * 128u + fo[ks]);
     };
-    auto mma = [&](int i, int j) {
+    auto mma = [&](int i, int j, const bf16x8 (&fb)[2][2]) {
         prio_hi();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -118,64 +127,50 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         prio_lo();
     };
 
-    const int nk = p.K / 64;
-    // prologue: the whole first K tile, then everybody meets once; group 1 then falls one barrier behind
+    // prologue: K tile 0 completely + A0, B0 of tile 1; wait for A0(0), B0(0); group 1 then falls one barrier behind
     issue(0, 0, 0);
     issue(0, 0, 1);
     issue(0, 0, 2);
     issue(0, 0, 3);
-    wait_vmcnt0();
+    issue(1, 1, 0);
+    issue(1, 1, 1);
+    wait_vmcnt<8>();
     g256_barrier();
     if (wr == 1) g256_barrier();
 
-    // one K tile; MORE = a next tile exists (its half-tiles are issued here).  The steady-state body is
-    // branch-free so the accumulators stay in place across the back-edge (no register copies).
-    auto ktile = [&](int kt, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
+#pragma nounroll
+    for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES;
-        // ---- phase 0: Q00 needs A0, B0 (landed: waited for in phase 3 of the previous tile / prologue)
+        // ---- phase 0: Q00 (A0, B0 landed: waited for in phase 3 of the previous tile / prologue)
         load_a(bufb, 0);
-        load_b(bufb, 0);
-        if constexpr (MORE) {
-            issue(cur ^ 1, kt + 1, 0);
-            wait_vmcnt<4>();   // B1 of THIS tile has landed (A1 + the new A0 stay in flight)
-        } else {
-            wait_vmcnt<2>();   // last tile: B1 landed, A1 in flight
-        }
+        load_b(bufb, 0, fb0);
+        issue(cur ^ 1, kt + 1, 2);   // B1(t+1)
+        wait_vmcnt<8>();             // B1(t) has landed
         g256_barrier();
-        mma(0, 0);
+        mma(0, 0, fb0);
         g256_barrier();
-        // ---- phase 1: Q01 needs B1
-        load_b(bufb, 1);
-        if constexpr (MORE) {
-            issue(cur ^ 1, kt + 1, 1);
-            wait_vmcnt<4>();   // A1 of THIS tile has landed
-        } else {
-            wait_vmcnt0();
-        }
+        // ---- phase 1: Q01
+        load_b(bufb, 1, fb1);
+        issue(cur ^ 1, kt + 1, 3);   // A1(t+1)
+        wait_vmcnt<8>();             // A1(t) has landed
         g256_barrier();
-        mma(0, 1);
+        mma(0, 1, fb1);
         g256_barrier();
-        // ---- phase 2: Q11 needs A1
+        // ---- phase 2: Q11
         load_a(bufb, 1);
-        if constexpr (MORE) issue(cur ^ 1, kt + 1, 2);
+        issue(cur, kt + 2, 0);       // A0(t+2) into THIS buffer: its A0 slot was last read in phase 0
         g256_barrier();
-        mma(1, 1);
+        mma(1, 1, fb1);
         g256_barrier();
-        // ---- phase 3: Q10 needs B0 again
-        load_b(bufb, 0);
-        if constexpr (MORE) {
-            issue(cur ^ 1, kt + 1, 3);
-            wait_vmcnt<4>();   // A0, B0 of the NEXT tile have landed (B1, A1 in flight)
-        }
+        // ---- phase 3: Q10 (B0 fragments still in registers: no LDS read)
+        issue(cur, kt + 2, 1);       // B0(t+2)
+        wait_vmcnt<8>();             // A0(t+1), B0(t+1) have landed
         g256_barrier();
-        mma(1, 0);
+        mma(1, 0, fb0);
         g256_barrier();
-    };
-#pragma nounroll
-    for (int kt = 0; kt + 1 < nk; ++kt) ktile(kt, TrueTag{});
-    ktile(nk - 1, FalseTag{});
+    }
+    wait_vmcnt0();   // drain the zero fills issued for the tiles past the end before LDS is released
     if (wr == 0) g256_barrier();   // re-balance the stagger
 
     // rows r = i*4 + mt, column groups g = j*2 + nt

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][nt][r] = 0.f;
-    bf16x8 fa[2][4], fb[4];   // [nt][ks], [ks]
+    bf16x8 fa[2][4], fb0[4], fb1[4];   // [nt][ks], [ks]; B0 fragments live for the whole step
 
     auto load_a = [&](uint32_t bufb, int i) {
 #pragma unroll
@@ -115,11 +115,11 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
 #pragma unroll
             for (uint32_t ks = 0; ks < 4; ++ks) fa[nt][ks] = tr_frag(bufb + (uint32_t)i * 16384u, (uint32_t)wr * 64 + nt * 32, ks);
     };
-    auto load_b = [&](uint32_t bufb, int j) {
+    auto load_b = [&](uint32_t bufb, int j, bf16x8 (&fb)[4]) {
 #pragma unroll
         for (uint32_t ks = 0; ks < 4; ++ks) fb[ks] = tr_frag(bufb + 32768u + (uint32_t)j * 16384u, (uint32_t)wc * 32, ks);
     };
-    auto mma = [&](int i, int j) {
+    auto mma = [&](int i, int j, const bf16x8 (&fb)[4]) {
         prio_hi();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -128,59 +128,47 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
         prio_lo();
     };
 
+    // same 5-6-phase-deep schedule as gemm256.h; steps past the end read rows >= M, i.e. zero fills
     const int nsteps = (M + 63) / 64;
     issue(0, 0);
     issue(0, 1);
     issue(0, 2);
     issue(0, 3);
-    wait_vmcnt0();
+    issue(1, 0);
+    issue(1, 1);
+    wait_vmcnt<8>();
     g256_barrier();
     if (wr == 1) g256_barrier();
 
-    // one K tile; MORE = a next tile exists (its half-tiles are issued here).  The steady-state body is
-    // branch-free so the accumulators stay in place across the back-edge (no register copies).
-    auto ktile = [&](int st, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
+#pragma nounroll
+    for (int st = 0; st < nsteps; ++st) {
         const int cur = st & 1;
         const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES;
         load_a(bufb, 0);
-        load_b(bufb, 0);
-        if constexpr (MORE) {
-            issue(cur ^ 1, 0);
-            wait_vmcnt<4>();
-        } else {
-            wait_vmcnt<2>();
-        }
+        load_b(bufb, 0, fb0);
+        issue(cur ^ 1, 2);   // B1(st+1)
+        wait_vmcnt<8>();
         g256_barrier();
-        mma(0, 0);
+        mma(0, 0, fb0);
         g256_barrier();
-        load_b(bufb, 1);
-        if constexpr (MORE) {
-            issue(cur ^ 1, 1);
-            wait_vmcnt<4>();
-        } else {
-            wait_vmcnt0();
-        }
+        load_b(bufb, 1, fb1);
+        issue(cur ^ 1, 3);   // A1(st+1)
+        wait_vmcnt<8>();
         g256_barrier();
-        mma(0, 1);
+        mma(0, 1, fb1);
         g256_barrier();
         load_a(bufb, 1);
-        if constexpr (MORE) issue(cur ^ 1, 2);
+        issue(cur, 0);       // A0(st+2)
         g256_barrier();
-        mma(1, 1);
+        mma(1, 1, fb1);
         g256_barrier();
-        load_b(bufb, 0);
-        if constexpr (MORE) {
-            issue(cur ^ 1, 3);
-            wait_vmcnt<4>();
-        }
+        issue(cur, 1);       // B0(st+2)
+        wait_vmcnt<8>();
         g256_barrier();
-        mma(1, 0);
+        mma(1, 0, fb0);
         g256_barrier();
-    };
-#pragma nounroll
-    for (int st = 0; st + 1 < nsteps; ++st) ktile(st, TrueTag{});
-    ktile(nsteps - 1, FalseTag{});
+    }
+    wait_vmcnt0();
     if (wr == 0) g256_barrier();
 
     // C += acc : D column = l&31 -> k (contiguous), row = (r&3) + 8(r>>2) + 4(l>>5) -> n
