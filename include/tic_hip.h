@@ -101,6 +101,21 @@ int tic_head_bwd(const float* dlogits, const void* z_bf16, const float* W, void*
 int tic_softmax_xent(const float* logits, const int64_t* labels, const float* soft, float* loss_sum,
                      float* dlogits, int B, int C, float gscale, tic_stream_t stream);
 
+/* On-GPU augmentation (replaces the CPU DataLoader transforms of ntrain.py:93-136, torchvision v2):
+ * images [B,Hs,Ws,3] uint8 -> out [B,3,S,S] fp32 normalised; params [B,20] fp32 per image:
+ *   0 top 1 left 2 h 3 w (crop box) 4 flip 5..8 ColorJitter op order (0 brightness 1 contrast 2 saturation 3 hue)
+ *   9 brightness 10 contrast 11 saturation 12 hue 13 jitter-on 14 grayscale-on 15 erase-on 16..19 erase box (i,j,h,w).
+ * mean3/std3 are HOST pointers to 3 floats (ImageNet stats, ntrain.py:111; dataset stats, preprocess.py:61-77). */
+#define TIC_AUG_NPARAM 20
+int tic_augment(const void* images_u8, int B, int Hs, int Ws, const float* params, float* out, int S,
+                const float* mean3, const float* std3, tic_stream_t stream);
+/* MixUp (mode 0: out = lam x + (1-lam) roll(x,1,0)) / CutMix (mode 1: box [y1,y2)x[x1,x2) pasted from roll(x,1,0));
+ * out-of-place.  ntrain.py:30-33,45-46 (torchvision v2.MixUp / v2.CutMix, alpha = 1). */
+int tic_mix(const float* x, float* out, int B, int C, int H, int W, int mode, float lam, int x1, int y1, int x2,
+            int y2, tic_stream_t stream);
+/* soft labels [B,ncls] = lam onehot(y) + (1-lam) onehot(roll(y,1)) */
+int tic_mix_labels(const int64_t* y, float* out, int B, int ncls, float lam, tic_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole-model step: one call enqueues every kernel of a phase (no per-op Python on the hot path).
  * Parameters, gradients, AdamW state and bf16 shadows live in caller-owned FLAT buffers with the

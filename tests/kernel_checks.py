@@ -227,3 +227,61 @@ def check_gemm_tn_group(env, M, shapes):
     call("tic_gemm_tn_group_bf16", n, PA, PB, PC, NN, KK, M, None)
     for c, r in zip(Cs, refs):
         torch.testing.assert_close(c, r, atol=2e-3 * max(1.0, (M / 200) ** 0.5), rtol=1e-3)
+
+
+def check_augment(env, S=32, H=40, W=48):
+    """HIP augmentation vs the float CPU restatement (oracle/aug_oracle.py) for explicit parameters"""
+    from oracle import aug_oracle as ao
+    import ctypes
+    dev, call = env.dev, env.call
+    g = torch.Generator().manual_seed(5)
+    cases = [
+        ao.AugParams(0, 0, H, W, jitter=False),                                                     # plain Resize (val/test)
+        ao.AugParams(3, 5, 30, 20, flip=True, order=(2, 0, 3, 1), brightness=1.15, contrast=0.85, saturation=1.1, hue=0.07, gray=False, erase=(4, 6, 10, 9)),
+        ao.AugParams(10, 0, 17, 48, flip=False, order=(1, 3, 0, 2), brightness=0.8, contrast=1.2, saturation=0.8, hue=-0.1, gray=True),
+        ao.AugParams(0, 8, 40, 33, flip=True, order=(3, 2, 1, 0), brightness=1.0, contrast=1.19, saturation=1.2, hue=0.0, erase=(0, 0, 31, 5)),
+    ]
+    B = len(cases)
+    imgs = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    P = torch.zeros(B, 20)
+    for b, c in enumerate(cases):
+        P[b, 0:4] = torch.tensor([c.top, c.left, c.height, c.width], dtype=torch.float32)
+        P[b, 4] = float(c.flip)
+        P[b, 5:9] = torch.tensor(c.order, dtype=torch.float32)
+        P[b, 9:13] = torch.tensor([c.brightness, c.contrast, c.saturation, c.hue])
+        P[b, 13], P[b, 14] = float(c.jitter), float(c.gray)
+        if c.erase is not None:
+            P[b, 15] = 1.0
+            P[b, 16:20] = torch.tensor(c.erase, dtype=torch.float32)
+    out = torch.empty(B, 3, S, S, device=dev)
+    mean = (ctypes.c_float * 3)(*ao.IMAGENET_MEAN)
+    std = (ctypes.c_float * 3)(*ao.IMAGENET_STD)
+    imgs_d, P_d = imgs.to(dev), P.to(dev)
+    call("tic_augment", ptr(imgs_d), B, H, W, ptr(P_d), ptr(out), S, mean, std, None)
+    for b, c in enumerate(cases):
+        ref = ao.augment_one(imgs[b], c, out=S)
+        # hue is discontinuous at sector boundaries: allow a few outlier pixels there, everything else tight
+        diff = (out[b].cpu() - ref).abs()
+        assert diff.median() < 1e-5 and (diff > 2e-3).float().mean() < 2e-3, (b, diff.max().item(), (diff > 2e-3).float().mean().item())
+
+
+def check_mix(env):
+    from oracle import aug_oracle as ao
+    dev, call, rnd = env.dev, env.call, env.rnd
+    B, C, H, W, ncls = 5, 3, 16, 24, 7
+    x = rnd(B, C, H, W)
+    y = torch.randint(0, ncls, (B,), device=dev)
+    out, soft = torch.empty_like(x), torch.empty(B, ncls, device=dev)
+    call("tic_mix", ptr(x), ptr(out), B, C, H, W, 0, 0.3, 0, 0, 0, 0, None)
+    call("tic_mix_labels", ptr(y), ptr(soft), B, ncls, 0.3, None)
+    rx, ry_ = ao.mixup(x.cpu(), y.cpu(), ncls, 0.3)
+    torch.testing.assert_close(out.cpu(), rx)
+    torch.testing.assert_close(soft.cpu(), ry_)
+    lam, cx, cy = 0.4, 17, 5
+    x1, y1, x2, y2 = ao.cutmix_box(H, W, lam, cx, cy)
+    call("tic_mix", ptr(x), ptr(out), B, C, H, W, 1, 0.0, x1, y1, x2, y2, None)
+    rx, ry_ = ao.cutmix(x.cpu(), y.cpu(), ncls, lam, cx, cy)
+    assert torch.equal(out.cpu(), rx)
+    lam_adj = 1.0 - (x2 - x1) * (y2 - y1) / float(W * H)
+    call("tic_mix_labels", ptr(y), ptr(soft), B, ncls, lam_adj, None)
+    torch.testing.assert_close(soft.cpu(), ry_)

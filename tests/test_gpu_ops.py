@@ -88,3 +88,12 @@ def test_gemm_tn_group(env, M, shapes):
         kc.check_gemm_tn_group(env, M, shapes)
     finally:
         call("tic_set_option", b"gemm_tile", 0)
+
+
+@pytest.mark.parametrize("S,H,W", [(32, 40, 48), (224, 256, 256)])
+def test_augment(env, S, H, W):
+    kc.check_augment(env, S, H, W) if S == 32 else kc.check_augment(env, S, H, W)
+
+
+def test_mix(env):
+    kc.check_mix(env)

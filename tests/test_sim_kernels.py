@@ -76,3 +76,11 @@ def test_gemm_tn_group(env, M, shapes):
         kc.check_gemm_tn_group(env, M, shapes)   # last case has a 128-multiple shape -> per-problem fallback
     finally:
         call("tic_set_option", b"gemm_tile", 0)
+
+
+def test_augment(env):
+    kc.check_augment(env)
+
+
+def test_mix(env):
+    kc.check_mix(env)

@@ -1,0 +1,200 @@
+"""MI355X-side counterpart of the reference's hand-rolled fine-tune harness (``TIC/ViT/finetune.py``).
+
+Same entry points, argument meaning and stop/checkpoint rules, re-built around the HIP hot path:
+
+  get_logger(name, log_dir)                                   finetune.py:21-52   file + stdout logger under log/
+  train_step(model, data, optimizer, criterion, scaler, scheduler=None) -> float    :54-67
+  validate_step(model, data, criterion) -> (float, int)       :69-77
+  early_exit(timeline, max_tolerant_epoch, logger) -> bool    :79-91
+  train_model(model, dataset, optimizer, scheduler, criterion, batch_size, num_epochs, max_tolerant_epoch,
+              save_path, logger, skip_optimizer_load=False, scheduler_per_epoch=True)            :93-268
+  get_linear_schedule_with_warmup(optimizer, warmup, total)   HF optimization.py:101-104 (used at finetune.py:324)
+
+Differences that are deliberate: the model computes in bf16 with fp32 accumulation natively, so
+the fp16 ``GradScaler`` of the reference is accepted for signature compatibility but never needed (pass ``None``
+or a disabled scaler); ``validate_step`` really runs under ``no_grad`` (the reference's ``no_grad() and autocast``
+expression never enters no_grad, finetune.py:71); the device is the model's device instead of a hard-coded "cuda".
+"""
+from __future__ import annotations
+
+import logging
+import math
+import os
+import sys
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch.utils.data import DataLoader, random_split
+
+
+def get_logger(name: str, log_dir: str = "log") -> logging.Logger:
+    os.makedirs(log_dir, exist_ok=True)
+    logger = logging.getLogger(name)
+    logger.setLevel(logging.INFO)
+    if logger.handlers:
+        return logger
+    fmt = logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    for handler in (logging.FileHandler(os.path.join(log_dir, f"{name}.log")), logging.StreamHandler(sys.stdout)):
+        handler.setLevel(logging.INFO)
+        handler.setFormatter(fmt)
+        logger.addHandler(handler)
+    return logger
+
+
+def get_linear_schedule_with_warmup(optimizer, num_warmup_steps: int, num_training_steps: int, last_epoch: int = -1):
+    """lr factor: step/warmup while warming up, then linear decay to 0 at num_training_steps."""
+    def factor(step: int) -> float:
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, factor, last_epoch)
+
+
+def _device_of(model) -> torch.device:
+    return next(model.parameters()).device
+
+
+def _logits_of(outputs):
+    return outputs.logits if hasattr(outputs, "logits") else outputs   # ViT returns an object, ResNet a tensor
+
+
+def train_step(model, data, optimizer, criterion, scaler=None, scheduler=None) -> float:
+    """One optimisation step; returns the loss as a Python float (this is the reference's per-step host sync)."""
+    model.train()
+    optimizer.zero_grad()
+    dev = _device_of(model)
+    inputs, labels = (t.to(dev, non_blocking=True) for t in data)
+    loss = criterion(_logits_of(model(inputs)), labels)
+    if scaler is not None and getattr(scaler, "is_enabled", lambda: False)():
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        loss.backward()
+        optimizer.step()
+    if scheduler:
+        scheduler.step()
+    return loss.item()
+
+
+def validate_step(model, data, criterion) -> Tuple[float, int]:
+    model.eval()
+    dev = _device_of(model)
+    with torch.no_grad():
+        inputs, labels = (t.to(dev, non_blocking=True) for t in data)
+        logits = _logits_of(model(inputs))
+        loss = criterion(logits, labels)
+        correct = (logits.argmax(dim=1) == labels).sum().item()
+    return loss.item(), correct
+
+
+def early_exit(timeline: Sequence[float], max_tolerant_epoch: int, logger) -> bool:
+    """Stop when at least N epochs are recorded and none of the last N validation losses is below the loss
+    N epochs earlier (the window start)."""
+    if len(timeline) < max_tolerant_epoch:
+        return False
+    window = list(timeline[-(max_tolerant_epoch + 1):])
+    anchor, rest = window[0], window[1:]
+    if all(v >= anchor for v in rest):
+        logger.info(f"Validation loss has not improved for {max_tolerant_epoch} epochs. Stopping training.")
+        return True
+    return False
+
+
+def _find_resume_epoch(save_path: str, num_epochs: int) -> int:
+    for e in range(num_epochs, 0, -1):
+        if os.path.exists(save_path.format(epoch=e)):
+            return e
+    return 0
+
+
+def _restore(model, optimizer, scheduler, ckpt, epoch: int, skip_optimizer_load: bool, scheduler_per_epoch: bool, logger) -> None:
+    """Checkpoint = (model_sd, optim_sd[, sched_sd]) tuple, or a bare model state_dict (older files)."""
+    if not (isinstance(ckpt, tuple) and len(ckpt) >= 2):
+        model.load_state_dict(ckpt)
+        logger.warning("Loaded checkpoint only contains model state_dict. Optimizer and scheduler state not loaded.")
+        return
+    model.load_state_dict(ckpt[0])
+    sched_state = ckpt[2] if len(ckpt) > 2 else None
+    if not skip_optimizer_load:
+        optimizer.load_state_dict(ckpt[1])
+        if scheduler and sched_state and scheduler_per_epoch:
+            scheduler.load_state_dict(sched_state)
+            logger.info("Loaded scheduler state.")
+        elif scheduler and not scheduler_per_epoch:
+            logger.warning("Resuming per-step scheduler state not fully implemented, may restart LR schedule.")
+    elif scheduler and scheduler_per_epoch:
+        logger.info(f"Skipping optimizer load, manually advancing scheduler to epoch {epoch}")
+        for _ in range(epoch):
+            scheduler.step()
+
+
+def _nan_guard(loss: float, running: float, i: int, what: str, epoch: int, logger) -> float:
+    if math.isnan(loss):
+        logger.warning(f"NaN loss detected at {what} step {i} in epoch {epoch + 1}. Replacing with avg loss.")
+        return running / (i + 1) if i > 0 else 0.0
+    return loss
+
+
+def train_model(model: torch.nn.Module, dataset, optimizer, scheduler, criterion, batch_size: int, num_epochs: int,
+                max_tolerant_epoch: int, save_path: str, logger: logging.Logger, skip_optimizer_load: bool = False,
+                scheduler_per_epoch: bool = True, num_workers: int = 8, val_fraction_denominator: int = 10) -> List[float]:
+    """Epoch loop with resume-from-latest, 90/10 split (seed 0), per-epoch tuple checkpoints and the early-exit rule.
+    Returns the validation-loss timeline."""
+    start_epoch = _find_resume_epoch(save_path, num_epochs)
+    if start_epoch:
+        logger.info(f"Resuming from epoch {start_epoch}")
+        ckpt = torch.load(save_path.format(epoch=start_epoch), map_location=_device_of(model), weights_only=False)
+        _restore(model, optimizer, scheduler, ckpt, start_epoch, skip_optimizer_load, scheduler_per_epoch, logger)
+    else:
+        logger.info("Starting training from scratch.")
+
+    n_val = len(dataset) // val_fraction_denominator
+    torch.manual_seed(0)   # split consistency across runs
+    train_set, val_set = random_split(dataset, [len(dataset) - n_val, n_val])
+    pin = _device_of(model).type == "cuda"
+    train_loader = DataLoader(train_set, batch_size=batch_size, shuffle=True, pin_memory=pin, num_workers=num_workers)
+    val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, pin_memory=pin, num_workers=num_workers)
+
+    def run_train(epoch: int) -> float:
+        if scheduler and scheduler_per_epoch:
+            logger.info(f"LR for epoch {epoch + 1}: {scheduler.get_last_lr()[0]:.6e}")
+        running = 0.0
+        for i, batch in enumerate(train_loader):
+            loss = train_step(model, batch, optimizer, criterion, None, None if scheduler_per_epoch else scheduler)
+            running += _nan_guard(loss, running, i, "training", epoch, logger)
+        return running / len(train_loader) if len(train_loader) else 0.0
+
+    def run_val(epoch: int) -> Tuple[float, float]:
+        optimizer.zero_grad(set_to_none=True)
+        running, correct, total = 0.0, 0, 0
+        for i, batch in enumerate(val_loader):
+            loss, c = validate_step(model, batch, criterion)
+            running += _nan_guard(loss, running, i, "validation", epoch, logger)
+            correct += c
+            total += len(batch[1])
+        return (running / len(val_loader) if len(val_loader) else 0.0), (100.0 * correct / total if total else 0.0)
+
+    if start_epoch:
+        logger.info(f"Validating model from loaded checkpoint (Epoch {start_epoch}) before resuming training...")
+        vl, acc = run_val(start_epoch - 1)
+        logger.info(f"Epoch [{start_epoch}], Validation Loss: {vl:.4f}, Accuracy: {acc:.2f}%")
+
+    timeline: List[float] = []
+    for epoch in range(start_epoch, num_epochs):
+        tl = run_train(epoch)
+        vl, acc = run_val(epoch)
+        timeline.append(vl)
+        state = (model.state_dict(), optimizer.state_dict())
+        if scheduler and scheduler_per_epoch:
+            state += (scheduler.state_dict(),)
+        path = save_path.format(epoch=epoch + 1)
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        torch.save(state, path)
+        logger.info(f"Checkpoint saved to {path}")
+        logger.info(f"Epoch [{epoch + 1}/{num_epochs}], Training Loss: {tl:.4f}, Validation Loss: {vl:.4f}, Accuracy: {acc:.2f}%")
+        if early_exit(timeline, max_tolerant_epoch, logger):
+            break
+        if scheduler and scheduler_per_epoch:
+            scheduler.step()
+    return timeline

@@ -59,6 +59,9 @@ SIGNATURES = {
     "tic_head_fwd": ([P, P, P, P, I, I, I, P], I),
     "tic_head_bwd": ([P, P, P, P, P, P, I, I, I, P], I),
     "tic_softmax_xent": ([P, P, P, P, P, I, I, F, P], I),
+    "tic_augment": ([P, I, I, I, P, P, I, C.POINTER(F), C.POINTER(F), P], I),
+    "tic_mix": ([P, P, I, I, I, I, I, F, I, I, I, I, P], I),
+    "tic_mix_labels": ([P, P, I, I, F, P], I),
     "tic_vit_layout": ([C.POINTER(TicVitDims), C.POINTER(TicVitLayout)], I),
     "tic_vit_refresh_weights": ([C.POINTER(TicVitState), I, P], I),
     "tic_vit_forward": ([C.POINTER(TicVitState), P, P, P], I),

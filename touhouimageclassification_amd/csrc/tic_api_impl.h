@@ -9,6 +9,7 @@
 
 #include "../../include/tic_hip.h"
 #include "attention.h"
+#include "aug.h"
 #include "elementwise.h"
 #include "gemm.h"
 #include "gemm256.h"
@@ -298,6 +299,32 @@ extern "C" int tic_softmax_xent(const float* logits, const int64_t* labels, cons
     TIC_REQUIRE((labels != nullptr) != (soft != nullptr), "softmax_xent: exactly one of labels / soft must be given");
     TIC_LAUNCH(xent_kernel, (B + 3) / 4, 256, 0, stream, logits, (const long long*)labels, soft, loss_sum, dlogits, B, C, gscale);
     return tic_after_launch("softmax_xent");
+}
+
+// ---- augmentation ----------------------------------------------------------------------------------
+extern "C" int tic_augment(const void* images_u8, int B, int Hs, int Ws, const float* params, float* out, int S,
+                           const float* mean3, const float* std3, tic_stream_t stream) {
+    TIC_REQUIRE(images_u8 && params && out && mean3 && std3, "augment: null pointer");
+    TIC_REQUIRE(B >= 1 && Hs >= 1 && Ws >= 1 && S >= 1, "augment: bad shape");
+    AugNorm nm;
+    for (int c = 0; c < 3; ++c) {
+        TIC_REQUIRE(std3[c] > 0.f, "augment: std must be positive");
+        nm.mean[c] = mean3[c];
+        nm.inv_std[c] = 1.0f / std3[c];
+    }
+    TIC_LAUNCH(augment_kernel, B, 256, 64, stream, (const unsigned char*)images_u8, Hs, Ws, params, out, S, nm);
+    return tic_after_launch("augment");
+}
+extern "C" int tic_mix(const float* x, float* out, int B, int C, int H, int W, int mode, float lam, int x1, int y1, int x2,
+                       int y2, tic_stream_t stream) {
+    TIC_REQUIRE(x && out && x != out && B >= 1 && W % 4 == 0 && (mode == 0 || mode == 1), "mix: bad argument (out of place, W %% 4 == 0)");
+    TIC_LAUNCH(mix_kernel, ew_grid((long)B * C * H * W / 4), 256, 0, stream, x, out, B, C, H, W, mode, lam, x1, y1, x2, y2);
+    return tic_after_launch("mix");
+}
+extern "C" int tic_mix_labels(const int64_t* y, float* out, int B, int ncls, float lam, tic_stream_t stream) {
+    TIC_REQUIRE(y && out && B >= 1 && ncls >= 1, "mix_labels: bad argument");
+    TIC_LAUNCH(mix_labels_kernel, (B * ncls + 255) / 256, 256, 0, stream, (const long long*)y, out, B, ncls, lam);
+    return tic_after_launch("mix_labels");
 }
 
 // ---- whole-model layout + phase drivers -------------------------------------------------------------

@@ -8,7 +8,6 @@ from typing import Optional
 
 import torch
 
-from . import ops
 from .dist import BucketedGradSync
 from .optim import FusedAdamW
 
@@ -19,7 +18,14 @@ def fused_train_step(model, optimizer: FusedAdamW, x: torch.Tensor, target: torc
     as device tensors (no .item(): the reference's per-step host sync, finetune.py:67, is the caller's choice)."""
     e = model._engine
     logits = e.forward(x)
-    loss, dlogits = ops.softmax_xent(logits, target, want_grad=True, gscale=sync.grad_scale if sync else 1.0)
+    B, C = logits.shape
+    loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    hard = target.dtype == torch.int64
+    tgt = target.contiguous() if hard else target.to(torch.float32).contiguous()
+    e.backend.call("tic_softmax_xent", logits.data_ptr(), tgt.data_ptr() if hard else None, None if hard else tgt.data_ptr(),
+                   loss.data_ptr(), dlogits.data_ptr(), B, C, sync.grad_scale if sync else 1.0, e.backend.stream())
+    loss = loss[0]
     e.grads.zero_()
     hook = None
     if model._bucket_hook is not None:
