@@ -41,7 +41,7 @@ int tic_set_option(const char* name, int value);
 #define TIC_EPI_DGELU 3 /* out = bf16(bf16(acc) * gelu'(aux))                       backward through GELU */
 #define TIC_EPI_PATCH 4 /* out_f32[(m/P)*(P+1)+1+m%P] = bf16(acc+bias) + rowtab[1+m%P]   patch embed + pos */
 
-/* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  N % 128 == 0, K % 64 == 0, any M >= 1.
+/* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  N % 8 == 0, K % 64 == 0, any M >= 1.
  * Replaces nn.Linear forward (HF:202-205,216-218,235-236,246-247,250-252) and, fed with W^T, the dX half
  * of its backward; EPI_PATCH replaces the patch Conv2d + position add (HF:60,69,146-157). */
 int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
@@ -49,7 +49,7 @@ int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int epil
                      const void* aux_bf16, const float* rowtab, int patches, tic_stream_t stream);
 
 /* C[N,K] += A[M,N]^T . B[M,K]  (fp32 accumulate into C; C holds the running gradient).
- * N % 128 == 0, K % 128 == 0.  Replaces the dW half of nn.Linear backward (autograd, finetune.py:62). */
+ * N % 8 == 0, K % 8 == 0.  Replaces the dW half of nn.Linear backward (autograd, finetune.py:62). */
 int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, tic_stream_t stream);
 /* the same for up to 4 problems sharing M (the four Linear layers of a transformer block) in ONE launch of
  * full-reduction 256x256 tiles (no split-K, no atomics) when shapes allow, else one launch per problem */
@@ -115,6 +115,32 @@ int tic_mix(const float* x, float* out, int B, int C, int H, int W, int mode, fl
             int y2, tic_stream_t stream);
 /* soft labels [B,ncls] = lam onehot(y) + (1-lam) onehot(roll(y,1)) */
 int tic_mix_labels(const int64_t* y, float* out, int B, int ncls, float lam, tic_stream_t stream);
+
+/* ---- ResNet conv path (TIC/ResNet/model.py; activations NHWC bf16, weights master fp32 OIHW) --------------
+ * A convolution is a GEMM over the kernels above: Y[M,Co] = col(X)[M,Kp] . Wp[Co,Kp]^T with M = B*Ho*Wo and
+ * Kp = kh*kw*Ci rounded up to 64 (tap-major k = (ky*kw+kx)*Ci + c); 1x1 stride-1 convs use X itself as col(X). */
+/* transposed != 0 writes [Kp, Co] (the B operand of the dgrad GEMM) */
+int tic_conv_weight_pack(const float* w_oihw, void* w16_ohwi, int Co, int Ci, int kh, int kw, int transposed, tic_stream_t stream); /* model.py:8-9,14,148 */
+int tic_conv_weight_grad(const float* dw_ohwi, float* grad_oihw, int Co, int Ci, int kh, int kw, tic_stream_t stream); /* grad += */
+int tic_nchw_to_nhwc_bf16(const float* x, void* out_bf16, int B, int C, int H, int W, tic_stream_t stream);
+int tic_im2col_bf16(const void* x, void* col, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, tic_stream_t stream);
+int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, int accumulate,
+                    tic_stream_t stream);
+/* BatchNorm2d over [M, C] bf16 (+ optional residual add, + optional ReLU): y = relu(bn(x) + identity).  train != 0: batch
+ * statistics, running stats (unbiased var) and num_batches_tracked updated; else running stats.  scratch2c: 2*C floats.
+ * model.py:51-52,60-61,99-113,150-151 */
+int tic_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      int64_t* num_batches, float* mean, float* rstd, float* scratch2c, const void* identity, void* y, long M, int C,
+                      float eps, float momentum, int train, int relu, tic_stream_t stream);
+/* dz = dy * [y > 0] (y_or_null = the block output when a ReLU follows); dx = BN'(dz); dskip (optional) (+)= dz; dgamma/dbeta += */
+int tic_batchnorm_bwd(const void* dy, const void* y_or_null, const void* x, const float* mean, const float* rstd, const float* gamma,
+                      float* scratch2c, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M, int C,
+                      tic_stream_t stream);
+int tic_maxpool3x3s2_fwd(const void* x, void* y, int B, int H, int W, int C, tic_stream_t stream);                       /* model.py:152 */
+int tic_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, tic_stream_t stream);
+int tic_avgpool_fwd(const void* x, void* y, int B, int HW, int C, tic_stream_t stream);                                  /* model.py:164,222 */
+int tic_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, tic_stream_t stream);
+int tic_add_bf16(void* a, const void* b, long n, tic_stream_t stream); /* a += b */
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-model step: one call enqueues every kernel of a phase (no per-op Python on the hot path).

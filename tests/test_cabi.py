@@ -28,8 +28,8 @@ def test_argument_validation_without_gpu():
     lib = ctypes.CDLL(build.build_hip())
     _capi.bind(lib)
     # N not a multiple of 128 -> TIC_EINVAL before any launch
-    rc = lib.tic_gemm_nt_bf16(16, 16, 10, 200, 64, 0, None, 16, None, None, None, None, None, 0, None)
-    assert rc == -1 and b"128" in lib.tic_last_error_string()
+    rc = lib.tic_gemm_nt_bf16(16, 16, 10, 200, 100, 0, None, 16, None, None, None, None, None, 0, None)
+    assert rc == -1 and b"K % 64" in lib.tic_last_error_string()
     rc = lib.tic_attention_fwd(16, 16, 16, 1, 1, 300, 0.125, None)
     assert rc == -1 and b"208" in lib.tic_last_error_string()
     d = _capi.TicVitDims(4, 1024, 16, 4096, 24, 120, 224, 16, 3, 1e-12)

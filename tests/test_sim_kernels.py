@@ -16,7 +16,7 @@ def env():
     return kc.Env("cpu", call)
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 128, 64), (130, 256, 192)])
+@pytest.mark.parametrize("M,N,K", [(200, 128, 64), (130, 256, 192), (100, 64, 64), (70, 200, 128)])
 def test_gemm_nt_bias_bf16(env, M, N, K):
     kc.check_gemm_nt_bias_bf16(env, M, N, K)
 
@@ -28,6 +28,11 @@ def test_gemm_nt_epilogues(env):
 @pytest.mark.parametrize("M", [64, 200, 333])
 def test_gemm_tn(env, M):
     kc.check_gemm_tn(env, M)
+
+
+def test_gemm_tn_ragged_nk(env):
+    kc.check_gemm_tn(env, 150, N=64, K=192)     # conv-shaped: Cout = 64, K = 3 x 64
+    kc.check_gemm_tn(env, 90, N=200, K=72)
 
 
 @pytest.mark.parametrize("D", [128, 768, 1024])

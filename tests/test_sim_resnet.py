@@ -1,0 +1,99 @@
+"""ResNet-18 (64x64, B=4) through the simulator backend vs the reference-generated golden file, plus kernel-level
+checks of the conv-path ops against torch."""
+import pytest
+import torch
+
+from tests import resnet_checks as rc
+from tests.simlib import SimBackend, bf, bfr, call, ptr
+
+
+def test_conv_ops_against_torch():
+    torch.manual_seed(0)
+    B, H, W, Ci, Co, k, s, p = 2, 9, 10, 16, 24, 3, 2, 1
+    x = bf(torch.randn(B, H, W, Ci))
+    w = torch.randn(Co, Ci, k, k) * 0.2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    Kp = (k * k * Ci + 63) // 64 * 64
+    col = torch.empty(B * Ho * Wo, Kp, dtype=torch.bfloat16)
+    call("tic_im2col_bf16", ptr(x), ptr(col), B, H, W, Ci, k, k, s, p, None)
+    wp, wpT = torch.empty(Co, Kp, dtype=torch.bfloat16), torch.empty(Kp, Co, dtype=torch.bfloat16)
+    call("tic_conv_weight_pack", ptr(w), ptr(wp), Co, Ci, k, k, 0, None)
+    call("tic_conv_weight_pack", ptr(w), ptr(wpT), Co, Ci, k, k, 1, None)
+    assert torch.equal(wp.t().contiguous(), wpT)
+    y = col.float() @ wp.float().t()
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), bfr(w), None, stride=s, padding=p).permute(0, 2, 3, 1).reshape(-1, Co)
+    torch.testing.assert_close(y, ref, atol=1e-3, rtol=1e-3)
+    # col2im = adjoint of im2col
+    dcol = bf(torch.randn(B * Ho * Wo, Kp))
+    dx = torch.empty(B * H * W, Ci, dtype=torch.bfloat16)
+    call("tic_col2im_bf16", ptr(dcol), ptr(dx), B, H, W, Ci, k, k, s, p, 0, None)
+    xr = x.float().requires_grad_(True)
+    colr = torch.nn.functional.unfold(xr.permute(0, 3, 1, 2), k, padding=p, stride=s)          # [B, Ci*k*k, L] (c-major)
+    colr = colr.view(B, Ci, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, k * k * Ci)  # -> tap-major
+    (colr * dcol.float()[:, :k * k * Ci]).sum().backward()
+    torch.testing.assert_close(dx.float().view(B, H, W, Ci), xr.grad, atol=0.05, rtol=0.02)
+    # weight gradient layout round trip
+    dwp = torch.randn(Co, Kp)
+    gr = torch.ones(Co, Ci, k, k)
+    call("tic_conv_weight_grad", ptr(dwp), ptr(gr), Co, Ci, k, k, None)
+    torch.testing.assert_close(gr - 1, dwp[:, :k * k * Ci].view(Co, k, k, Ci).permute(0, 3, 1, 2))
+
+
+def test_batchnorm_and_pools_against_torch():
+    torch.manual_seed(1)
+    B, H, W, C = 3, 8, 6, 16
+    M = B * H * W
+    x = bf(torch.randn(M, C) * 2 + 0.3)
+    ident = bf(torch.randn(M, C))
+    gamma, beta = 1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C)
+    rm, rv, nb = torch.zeros(C), torch.ones(C), torch.tensor(0)
+    mean, rstd, scr = torch.empty(C), torch.empty(C), torch.empty(2 * C)
+    y = torch.empty(M, C, dtype=torch.bfloat16)
+    call("tic_batchnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nb), ptr(mean), ptr(rstd), ptr(scr), ptr(ident), ptr(y), M, C, 1e-5, 0.1, 1, 1, None)
+    xr = x.float().requires_grad_(True)
+    gr, br, ir = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), ident.float().requires_grad_(True)
+    bn = torch.nn.functional.batch_norm(xr, torch.zeros(C), torch.ones(C), gr, br, True, 0.1, 1e-5)
+    ref = torch.relu(bn + ir)
+    torch.testing.assert_close(y.float(), ref.detach(), atol=0.03, rtol=0.02)
+    torch.testing.assert_close(rm, 0.1 * x.float().mean(0), atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(rv, 0.9 + 0.1 * x.float().var(0, unbiased=True), atol=1e-4, rtol=1e-4)
+    assert int(nb) == 1
+    dy = bf(torch.randn(M, C))
+    ref.backward(dy.float())
+    dx, dskip = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+    dg, db = torch.zeros(C), torch.zeros(C)
+    call("tic_batchnorm_bwd", ptr(dy), ptr(y), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(scr), ptr(dx), ptr(dskip), 0, ptr(dg), ptr(db), M, C, None)
+    # the ReLU mask comes from the bf16 output; compare where the reference is not at the kink
+    torch.testing.assert_close(dx.float(), xr.grad, atol=0.06, rtol=0.05)
+    torch.testing.assert_close(dskip.float(), ir.grad, atol=0.02, rtol=0.02)
+    torch.testing.assert_close(dg, gr.grad, atol=0.05, rtol=0.02)
+    torch.testing.assert_close(db, br.grad, atol=0.05, rtol=0.02)
+    # pools
+    xp = bf(torch.randn(B, H, W, C))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    yp = torch.empty(B, Ho, Wo, C, dtype=torch.bfloat16)
+    call("tic_maxpool3x3s2_fwd", ptr(xp), ptr(yp), B, H, W, C, None)
+    xpr = xp.float().permute(0, 3, 1, 2).requires_grad_(True)
+    mp = torch.nn.functional.max_pool2d(xpr, 3, 2, 1)
+    assert torch.equal(yp.float(), mp.detach().permute(0, 2, 3, 1))
+    dyp = bf(torch.randn(B, Ho, Wo, C))
+    mp.backward(dyp.float().permute(0, 3, 1, 2))
+    dxp = torch.empty(B, H, W, C, dtype=torch.bfloat16)
+    call("tic_maxpool3x3s2_bwd", ptr(xp), ptr(yp), ptr(dyp), ptr(dxp), B, H, W, C, None)
+    torch.testing.assert_close(dxp.float(), xpr.grad.permute(0, 2, 3, 1), atol=0.02, rtol=0.01)
+    z = torch.empty(B, C, dtype=torch.bfloat16)
+    call("tic_avgpool_fwd", ptr(xp), ptr(z), B, H * W, C, None)
+    torch.testing.assert_close(z.float(), xp.float().mean((1, 2)), atol=0.01, rtol=0.01)
+    dxa = torch.empty(B, H * W, C, dtype=torch.bfloat16)
+    call("tic_avgpool_bwd", ptr(z), ptr(dxa), B, H * W, C, None)
+    torch.testing.assert_close(dxa.float(), (z.float() / (H * W)).unsqueeze(1).expand(B, H * W, C), atol=1e-3, rtol=0.01)
+    a, b2 = bf(torch.randn(64)), bf(torch.randn(64))
+    exp = bf(a.float() + b2.float())
+    call("tic_add_bf16", ptr(a), ptr(b2), 64, None)
+    assert torch.equal(a, exp)
+
+
+@pytest.mark.timeout(900)
+def test_resnet18_step_matches_reference_golden(golden_dir):
+    worst = rc.check_against_golden("resnet18", golden_dir, SimBackend(), torch.device("cpu"), logit_tol=5e-2, gnorm_tol=0.12)
+    print("worst grad-norm rel err", worst)

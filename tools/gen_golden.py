@@ -105,47 +105,48 @@ def gen_vit_full(tag, base, C, B, seed):
 
 
 def gen_resnet():
+    """Reference = /root/reference/TIC/ResNet/model.py itself.  Weights come from the oracle's seeded init (so tests can
+    regenerate them without the reference); the comparison runs in float64, where the reference and the restatement
+    agree to ~1e-10 -- in fp32 a random-init ResNet-50 at small batch is ill-conditioned (ReLU mask flips move single
+    gradient entries by 20 % between two correct fp32 implementations; both sit 2.5 % from the fp64 result)."""
     sys.path.insert(0, "/root/reference")
     from TIC.ResNet import model as ref   # reference file, torch only
     from oracle import resnet_oracle as ro
-    for name, B, C, img, full in (("resnet18", 2, 10, 64, True), ("resnet50", 4, 10, 224, False)):
-        torch.manual_seed(0)
-        m = getattr(ref, name)(num_classes=C).train()
-        # non-trivial BN affine so gamma/beta paths are exercised
+    for name, B, C, img in (("resnet18", 4, 10, 64), ("resnet50", 8, 10, 224)):
+        sd = ro.init_state(name, C, seed=3)
         g = torch.Generator().manual_seed(7)
-        with torch.no_grad():
-            for k, p in m.named_parameters():
-                if p.ndim == 1:
-                    p.add_(torch.empty_like(p).normal_(0, 0.05, generator=g))
-        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        for k in sd:   # non-trivial BN affine / running stats so those paths are exercised
+            if sd[k].ndim == 1 and sd[k].is_floating_point() and not k.startswith("fc"):
+                sd[k] = sd[k] + torch.empty_like(sd[k]).normal_(0, 0.05, generator=g)
         x = torch.randn(B, 3, img, img, generator=g)
         y = torch.randint(0, C, (B,), generator=g)
-        logits = m(x)
+        m = getattr(ref, name)(num_classes=C).double().train()
+        m.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+        logits = m(x.double())
         loss = torch.nn.functional.cross_entropy(logits, y)
         loss.backward()
         grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
         after = {k: v.detach().clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
-        o_logits, o_loss, o_grads, o_after = ro.loss_and_grads(sd, x, y, name)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        o_logits, o_loss, o_grads, o_after = ro.loss_and_grads(sd64, x.double(), y, name)
         err = (logits.detach() - o_logits).abs().max().item()
-        gerr = max((grads[k] - o_grads[k]).abs().max().item() / (grads[k].abs().max().item() + 1e-12) for k in grads)
-        rerr = max((after[k].float() - o_after[k].float()).abs().max().item() for k in after)
-        print(f"[{name}] oracle-vs-reference logits max|d|={err:.2e} grads rel={gerr:.2e} running-stats d={rerr:.2e}")
-        assert err < 1e-4 and gerr < 1e-3 and rerr < 1e-5
-        out = {"x": x.numpy(), "y": y.numpy(), "logits": logits.detach().numpy(), "loss": np.float32(loss.item())}
+        gerr = max((grads[k] - o_grads[k]).norm().item() / (grads[k].norm().item() + 1e-30) for k in grads)
+        rerr = max((after[k].double() - o_after[k].double()).abs().max().item() for k in after)
+        print(f"[{name}] oracle-vs-reference (fp64) logits max|d|={err:.2e} grads rel={gerr:.2e} running-stats d={rerr:.2e}")
+        assert err < 1e-9 and gerr < 1e-8 and rerr < 1e-10
+        assert list(sd.keys()) == list(m.state_dict().keys()), "state_dict key order differs from the reference"
+        # the fp32 oracle against this fp64 truth, for the record (what a correct fp32 implementation achieves)
+        f_logits, _, f_grads, _ = ro.loss_and_grads(sd, x, y, name)
+        print(f"          fp32 oracle vs fp64: logits {(f_logits.double() - logits.detach()).abs().max().item():.2e}, "
+              f"worst grad norm-rel {max((f_grads[k].double() - grads[k]).norm().item() / (grads[k].norm().item() + 1e-30) for k in grads):.2e}")
         names = list(grads.keys())
-        out["grad_norm_names"] = np.array(names)
-        out["grad_norms"] = np.array([grads[k].norm().item() for k in names], np.float64)
+        out = {"seed": 3, "B": B, "C": C, "img": img, "y": y.numpy(), "x_checksum": np.float64(x.double().sum().item()),
+               "logits": logits.detach().numpy(), "loss": np.float64(loss.item()),
+               "grad_norm_names": np.array(names), "grad_norms": np.array([grads[k].norm().item() for k in names], np.float64)}
         for k, v in after.items():
             out[f"after/{k}"] = v.numpy()
-        if full:
-            for k, v in sd.items():
-                out[f"state/{k}"] = v.numpy()
-            for k, v in grads.items():
-                out[f"grad/{k}"] = v.numpy()
-        else:
-            out["seed_note"] = np.array("weights = reference init under torch.manual_seed(0) + N(0,.05) on 1-D params (gen 7); stored as state/ for 1-D only")
-            for k, v in sd.items():
-                out[f"state/{k}"] = v.numpy().astype(np.float16) if v.ndim == 4 else v.numpy()
+        for k in ("conv1.weight", "fc.weight", "fc.bias", "bn1.weight", "layer1.0.conv1.weight"):
+            out[f"grad/{k}"] = grads[k].numpy().astype(np.float32)
         np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
 
 

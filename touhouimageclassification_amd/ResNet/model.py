@@ -1,0 +1,297 @@
+"""Drop-in for the reference's ``TIC/ResNet/model.py``: ``resnet18/34/50/101/152(pretrained=False, progress=True,
+num_classes=1000, **kw)`` returning an ``nn.Module`` that maps ``[B,3,H,W]`` fp32 to a raw ``[B,C]`` tensor
+(TIC/ResNet/model.py:249-276, used at TIC/ResNet/train.py:52,239), with the reference's ``state_dict`` keys
+(conv1.weight, bn1.{weight,bias,running_mean,running_var,num_batches_tracked}, layerN.i.convK/bnK/downsample.{0,1}, fc.*).
+
+Forward and backward run in libtic_hip.so: NHWC bf16 activations, every convolution a bf16 MFMA GEMM (1x1 stride-1
+directly on the activation, the rest through im2col), train-mode BatchNorm (+ReLU, +residual) / pools as HIP kernels,
+fp32 master weights and fp32 gradient accumulation.  Blocks follow model.py:17-63 (BasicBlock) and :66-115
+(Bottleneck, stride on the 3x3), stages / downsample follow ``_make_layer`` :185-208, init follows :168-183.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ..engine import _HipBackend
+
+_CFG = {"resnet18": ("basic", [2, 2, 2, 2]), "resnet34": ("basic", [3, 4, 6, 3]), "resnet50": ("bottleneck", [3, 4, 6, 3]),
+        "resnet101": ("bottleneck", [3, 4, 23, 3]), "resnet152": ("bottleneck", [3, 8, 36, 3])}
+_EPS, _MOMENTUM = 1e-5, 0.1
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, k, stride, pad):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode='fan_out', nonlinearity='relu')   # model.py:170
+        self.weight = nn.Parameter(w)
+
+    @property
+    def kp(self):
+        return (self.k * self.k * self.cin + 63) // 64 * 64
+
+
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _FC(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        lin = nn.Linear(cin, cout)   # default nn.Linear init, as the reference (model.py:165)
+        self.weight, self.bias = lin.weight, lin.bias
+
+
+class _Block(nn.Module):
+    def __init__(self, kind, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.kind = kind
+        if kind == "basic":
+            self.conv1, self.bn1 = _Conv(inplanes, planes, 3, stride, 1), _BN(planes)
+            self.conv2, self.bn2 = _Conv(planes, planes, 3, 1, 1), _BN(planes)
+            out = planes
+        else:
+            self.conv1, self.bn1 = _Conv(inplanes, planes, 1, 1, 0), _BN(planes)
+            self.conv2, self.bn2 = _Conv(planes, planes, 3, stride, 1), _BN(planes)
+            self.conv3, self.bn3 = _Conv(planes, planes * 4, 1, 1, 0), _BN(planes * 4)
+            out = planes * 4
+        self.downsample = nn.Sequential(_Conv(inplanes, out, 1, stride, 0), _BN(out)) if downsample else None
+
+
+class _ResNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x, module):
+        ctx.module = module
+        logits, ctx.tape = module._forward_impl(x, train=module.training, record=True)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.module._backward_impl(dlogits.contiguous().float(), ctx.tape)
+        ctx.tape = None
+        return None, None, None
+
+
+class TicResNet(nn.Module):
+    def __init__(self, arch: str, num_classes: int = 1000, zero_init_residual: bool = False, backend=None, **unsupported):
+        super().__init__()
+        for k in ("groups", "width_per_group", "replace_stride_with_dilation", "norm_layer"):
+            if unsupported.get(k) not in (None, 1, 64, [False, False, False]):
+                raise NotImplementedError(f"TIC HIP ResNet supports the reference's defaults only ({k} given)")
+        kind, counts = _CFG[arch]
+        self.arch, self.num_classes = arch, num_classes
+        self.backend = backend or _HipBackend()
+        self.conv1, self.bn1 = _Conv(3, 64, 7, 2, 3), _BN(64)
+        inplanes, exp = 64, (1 if kind == "basic" else 4)
+        for si, (planes, n) in enumerate(zip([64, 128, 256, 512], counts)):
+            blocks = []
+            for bi in range(n):
+                stride = 2 if (bi == 0 and si > 0) else 1
+                blocks.append(_Block(kind, inplanes, planes, stride, bi == 0 and (stride != 1 or inplanes != planes * exp)))
+                inplanes = planes * exp
+            setattr(self, f"layer{si + 1}", nn.Sequential(*blocks))
+        self.fc = _FC(inplanes, num_classes)
+        if zero_init_residual:   # model.py:178-183
+            for m in self.modules():
+                if isinstance(m, _Block):
+                    nn.init.constant_((m.bn3 if m.kind == "bottleneck" else m.bn2).weight, 0)
+        self._anchor = torch.zeros(1, requires_grad=True)
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn)
+        self._anchor = torch.zeros(1, requires_grad=True, device=self.fc.weight.device)
+        return self
+
+    # ---- thin op wrappers over the C ABI ---------------------------------------------------------------------
+    def _call(self, name, *args):
+        self.backend.call(name, *args, self.backend.stream())
+
+    def _gemm_nt(self, A, Bw, M, N, K):
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
+        self._call("tic_gemm_nt_bf16", A.data_ptr(), Bw.data_ptr(), M, N, K, 0, None, out.data_ptr(), None, None, None, None, None, 0)
+        return out
+
+    def _pack(self, conv: _Conv, transposed: bool):
+        kp = conv.kp
+        out = torch.empty((kp, conv.cout) if transposed else (conv.cout, kp), dtype=torch.bfloat16, device=conv.weight.device)
+        self._call("tic_conv_weight_pack", conv.weight.data_ptr(), out.data_ptr(), conv.cout, conv.cin, conv.k, conv.k, 1 if transposed else 0)
+        return out
+
+    def _conv_fwd(self, conv: _Conv, x, B, H, W):
+        """x [B,H,W,Cin] bf16 -> (y [M,Cout] bf16, col or None, Ho, Wo)"""
+        Ho = (H + 2 * conv.pad - conv.k) // conv.stride + 1
+        Wo = (W + 2 * conv.pad - conv.k) // conv.stride + 1
+        M = B * Ho * Wo
+        if conv.k == 1 and conv.stride == 1:
+            col = x
+        else:
+            col = torch.empty(M, conv.kp, dtype=torch.bfloat16, device=x.device)
+            self._call("tic_im2col_bf16", x.data_ptr(), col.data_ptr(), B, H, W, conv.cin, conv.k, conv.k, conv.stride, conv.pad)
+        return self._gemm_nt(col, self._pack(conv, False), M, conv.cout, conv.kp), col, Ho, Wo
+
+    def _bn_fwd(self, bn: _BN, x, M, identity, relu, train):
+        dev = x.device
+        mean, rstd = torch.empty(bn.c, device=dev), torch.empty(bn.c, device=dev)
+        scratch = torch.empty(2 * bn.c, device=dev)
+        y = torch.empty_like(x)
+        self._call("tic_batchnorm_fwd", x.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                   bn.num_batches_tracked.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(),
+                   None if identity is None else identity.data_ptr(), y.data_ptr(), M, bn.c, _EPS, _MOMENTUM, 1 if train else 0, 1 if relu else 0)
+        return y, mean, rstd
+
+    @staticmethod
+    def _grad_buf(p: nn.Parameter):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        return p.grad
+
+    def _conv_bwd(self, conv: _Conv, dy, col, B, H, W, need_dx: bool, dx_accumulate_into=None):
+        """dy [M,Cout]; returns dx [B*H*W, Cin] bf16 (or None) and accumulates the weight gradient"""
+        M = dy.shape[0]
+        dw = torch.zeros(conv.cout, conv.kp, dtype=torch.float32, device=dy.device)
+        self._call("tic_gemm_tn_bf16", dy.data_ptr(), col.data_ptr(), dw.data_ptr(), M, conv.cout, conv.kp)
+        self._call("tic_conv_weight_grad", dw.data_ptr(), self._grad_buf(conv.weight).data_ptr(), conv.cout, conv.cin, conv.k, conv.k)
+        if not need_dx:
+            return None
+        dcol = self._gemm_nt(dy, self._pack(conv, True), M, conv.kp, conv.cout)
+        if conv.k == 1 and conv.stride == 1:
+            if dx_accumulate_into is not None:
+                self._call("tic_add_bf16", dx_accumulate_into.data_ptr(), dcol.data_ptr(), dcol.numel())
+                return dx_accumulate_into
+            return dcol
+        dx = dx_accumulate_into if dx_accumulate_into is not None else torch.empty(B * H * W, conv.cin, dtype=torch.bfloat16, device=dy.device)
+        self._call("tic_col2im_bf16", dcol.data_ptr(), dx.data_ptr(), B, H, W, conv.cin, conv.k, conv.k, conv.stride, conv.pad,
+                   1 if dx_accumulate_into is not None else 0)
+        return dx
+
+    def _bn_bwd(self, bn: _BN, dy, y_relu, x, mean, rstd, M, dskip=None, skip_accumulate=False):
+        dx = torch.empty_like(x)
+        scratch = torch.empty(2 * bn.c, device=x.device)
+        self._call("tic_batchnorm_bwd", dy.data_ptr(), None if y_relu is None else y_relu.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                   bn.weight.data_ptr(), scratch.data_ptr(), dx.data_ptr(), None if dskip is None else dskip.data_ptr(), 1 if skip_accumulate else 0,
+                   self._grad_buf(bn.weight).data_ptr(), self._grad_buf(bn.bias).data_ptr(), M, bn.c)
+        return dx
+
+    # ---- forward / backward -----------------------------------------------------------------------------------------
+    def _blocks(self) -> List[_Block]:
+        return [b for i in range(1, 5) for b in getattr(self, f"layer{i}")]
+
+    def _forward_impl(self, x: torch.Tensor, train: bool, record: bool):
+        self.backend.check_tensor(x)
+        B, C, H, W = x.shape
+        if C != 3:
+            raise ValueError(f"expected 3 input channels, got {C}")
+        x = x.to(torch.float32).contiguous()
+        tape: Dict = {"B": B, "blocks": []}
+        xin = torch.empty(B, H, W, 3, dtype=torch.bfloat16, device=x.device)
+        self._call("tic_nchw_to_nhwc_bf16", x.data_ptr(), xin.data_ptr(), B, 3, H, W)
+        c0, col0, H1, W1 = self._conv_fwd(self.conv1, xin, B, H, W)
+        a0, m0, r0 = self._bn_fwd(self.bn1, c0, B * H1 * W1, None, True, train)
+        Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
+        h = torch.empty(B * Hp * Wp, 64, dtype=torch.bfloat16, device=x.device)
+        self._call("tic_maxpool3x3s2_fwd", a0.data_ptr(), h.data_ptr(), B, H1, W1, 64)
+        tape["stem"] = (col0, c0, a0, m0, r0, H, W, H1, W1, h)
+        Hc, Wc = Hp, Wp
+        for blk in self._blocks():
+            rec = {"in": h, "H": Hc, "W": Wc}
+            convs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)] + ([(blk.conv3, blk.bn3)] if blk.kind == "bottleneck" else [])
+            if blk.downsample is not None:
+                cd, cold, Hd, Wd = self._conv_fwd(blk.downsample[0], h, B, Hc, Wc)
+                identity, md, rd = self._bn_fwd(blk.downsample[1], cd, B * Hd * Wd, None, False, train)
+                rec["ds"] = (cold, cd, md, rd)
+            else:
+                identity = h
+            t, Ht, Wt = h, Hc, Wc
+            steps = []
+            for i, (cv, bn) in enumerate(convs):
+                last = i == len(convs) - 1
+                c, col, Ho, Wo = self._conv_fwd(cv, t, B, Ht, Wt)
+                y, m, r = self._bn_fwd(bn, c, B * Ho * Wo, identity if last else None, True, train)
+                steps.append((col, c, y, m, r, Ht, Wt))
+                t, Ht, Wt = y, Ho, Wo
+            rec["steps"] = steps
+            tape["blocks"].append(rec)
+            h, Hc, Wc = t, Ht, Wt
+        feat = self.fc.weight.shape[1]
+        z = torch.empty(B, feat, dtype=torch.bfloat16, device=x.device)
+        self._call("tic_avgpool_fwd", h.data_ptr(), z.data_ptr(), B, Hc * Wc, feat)
+        logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=x.device)
+        self._call("tic_head_fwd", z.data_ptr(), self.fc.weight.data_ptr(), self.fc.bias.data_ptr(), logits.data_ptr(), B, self.num_classes, feat)
+        tape["head"] = (z, Hc, Wc, feat)
+        return logits, (tape if record else None)
+
+    def _backward_impl(self, dlogits: torch.Tensor, tape):
+        B = tape["B"]
+        z, Hc, Wc, feat = tape["head"]
+        dev = dlogits.device
+        dz = torch.empty(B, feat, dtype=torch.bfloat16, device=dev)
+        self._call("tic_head_bwd", dlogits.data_ptr(), z.data_ptr(), self.fc.weight.data_ptr(), dz.data_ptr(), self._grad_buf(self.fc.weight).data_ptr(),
+                   self._grad_buf(self.fc.bias).data_ptr(), B, self.num_classes, feat)
+        dh = torch.empty(B * Hc * Wc, feat, dtype=torch.bfloat16, device=dev)
+        self._call("tic_avgpool_bwd", dz.data_ptr(), dh.data_ptr(), B, Hc * Wc, feat)
+        for blk, rec in zip(reversed(self._blocks()), reversed(tape["blocks"])):
+            convs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)] + ([(blk.conv3, blk.bn3)] if blk.kind == "bottleneck" else [])
+            steps = rec["steps"]
+            dident = torch.empty_like(dh)   # gradient of the identity / downsample branch = masked block-output gradient
+            d = dh
+            for i in reversed(range(len(convs))):
+                cv, bn = convs[i]
+                col, c, y, m, r, Hi, Wi = steps[i]
+                last = i == len(convs) - 1
+                d = self._bn_bwd(bn, d, y, c, m, r, c.shape[0], dskip=dident if last else None)
+                d = self._conv_bwd(cv, d, col, B, Hi, Wi, need_dx=True)
+            if blk.downsample is not None:
+                cold, cd, md, rd = rec["ds"]
+                dd = self._bn_bwd(blk.downsample[1], dident, None, cd, md, rd, cd.shape[0])
+                self._conv_bwd(blk.downsample[0], dd, cold, B, rec["H"], rec["W"], need_dx=True, dx_accumulate_into=d)
+            else:
+                self._call("tic_add_bf16", d.data_ptr(), dident.data_ptr(), d.numel())
+            dh = d
+        col0, c0, a0, m0, r0, H, W, H1, W1, hpool = tape["stem"]
+        da0 = torch.empty_like(a0)
+        self._call("tic_maxpool3x3s2_bwd", a0.data_ptr(), hpool.data_ptr(), dh.data_ptr(), da0.data_ptr(), B, H1, W1, 64)
+        dc0 = self._bn_bwd(self.bn1, da0, a0, c0, m0, r0, c0.shape[0])
+        self._conv_bwd(self.conv1, dc0, col0, B, H, W, need_dx=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            return _ResNetFunction.apply(self._anchor, x, self)
+        return self._forward_impl(x, train=self.training, record=False)[0]
+
+
+def _resnet(arch: str, pretrained: bool, progress: bool, **kwargs) -> TicResNet:
+    # the reference ignores `pretrained` (weights are loaded outside the model definition, model.py:241-245)
+    return TicResNet(arch, **kwargs)
+
+
+def resnet18(pretrained: bool = False, progress: bool = True, num_classes: int = 1000, **kwargs) -> TicResNet:
+    return _resnet('resnet18', pretrained, progress, num_classes=num_classes, **kwargs)
+
+
+def resnet34(pretrained: bool = False, progress: bool = True, num_classes: int = 1000, **kwargs) -> TicResNet:
+    return _resnet('resnet34', pretrained, progress, num_classes=num_classes, **kwargs)
+
+
+def resnet50(pretrained: bool = False, progress: bool = True, num_classes: int = 1000, **kwargs) -> TicResNet:
+    return _resnet('resnet50', pretrained, progress, num_classes=num_classes, **kwargs)
+
+
+def resnet101(pretrained: bool = False, progress: bool = True, num_classes: int = 1000, **kwargs) -> TicResNet:
+    return _resnet('resnet101', pretrained, progress, num_classes=num_classes, **kwargs)
+
+
+def resnet152(pretrained: bool = False, progress: bool = True, num_classes: int = 1000, **kwargs) -> TicResNet:
+    return _resnet('resnet152', pretrained, progress, num_classes=num_classes, **kwargs)

@@ -62,6 +62,18 @@ SIGNATURES = {
     "tic_augment": ([P, I, I, I, P, P, I, C.POINTER(F), C.POINTER(F), P], I),
     "tic_mix": ([P, P, I, I, I, I, I, F, I, I, I, I, P], I),
     "tic_mix_labels": ([P, P, I, I, F, P], I),
+    "tic_conv_weight_pack": ([P, P, I, I, I, I, I, P], I),
+    "tic_conv_weight_grad": ([P, P, I, I, I, I, P], I),
+    "tic_nchw_to_nhwc_bf16": ([P, P, I, I, I, I, P], I),
+    "tic_im2col_bf16": ([P, P, I, I, I, I, I, I, I, I, P], I),
+    "tic_col2im_bf16": ([P, P, I, I, I, I, I, I, I, I, I, P], I),
+    "tic_batchnorm_fwd": ([P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, I, P], I),
+    "tic_batchnorm_bwd": ([P, P, P, P, P, P, P, P, P, I, P, P, L, I, P], I),
+    "tic_maxpool3x3s2_fwd": ([P, P, I, I, I, I, P], I),
+    "tic_maxpool3x3s2_bwd": ([P, P, P, P, I, I, I, I, P], I),
+    "tic_avgpool_fwd": ([P, P, I, I, I, P], I),
+    "tic_avgpool_bwd": ([P, P, I, I, I, P], I),
+    "tic_add_bf16": ([P, P, L, P], I),
     "tic_vit_layout": ([C.POINTER(TicVitDims), C.POINTER(TicVitLayout)], I),
     "tic_vit_refresh_weights": ([C.POINTER(TicVitState), I, P], I),
     "tic_vit_forward": ([C.POINTER(TicVitState), P, P, P], I),

@@ -1,0 +1,384 @@
+// conv.h -- the ResNet conv stack of TIC/ResNet/model.py on gfx950 (NHWC bf16 activations).
+//
+// Convolutions are GEMMs over the MFMA kernels of gemm.h / gemm256.h / gemm_tn256.h:
+//   forward   Y[M, Co]   = col(X)[M, Kp] . W[Co, Kp]^T        M = B*Ho*Wo, K = kh*kw*Ci (tap-major, padded to 64)
+//   dgrad     dcol[M,Kp] = dY[M, Co] . (W^T)[Kp, Co]^T ; dX = col2im(dcol)   (gather form: no atomics)
+//   wgrad     dW[Co, Kp] += dY^T . col(X)
+// 1x1 stride-1 convs (most of a Bottleneck) need no im2col at all: the NHWC activation IS the GEMM operand.
+// Round 1 materialises col(X) for k > 1 / strided convs (explicit im2col: 9x the activation bytes for a 3x3);
+// folding the gather into the LDS-DMA source addresses (implicit GEMM) is the next step for this path.
+// Replaces conv3x3 / conv1x1 / the 7x7 stem (TIC/ResNet/model.py:6-14,148), train-mode BatchNorm2d + ReLU
+// (+ residual add) (:51-61,99-113,150-151), MaxPool2d(3,2,1) (:152), AdaptiveAvgPool2d(1) (:164) and their backward.
+#pragma once
+#include "norm.h"
+
+struct ConvGeom {
+    int B, H, W, Ci, Ho, Wo, kh, kw, stride, pad, K, Kp;   // K = kh*kw*Ci, Kp = K rounded up to 64
+};
+
+// OIHW fp32 -> [Co, Kp] bf16 with k = (ky*kw + kx)*Ci + c, zero padded; transposed != 0 writes [Kp, Co] (dgrad operand)
+__global__ void __launch_bounds__(256) weight_ohwi_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Co, ConvGeom g, int transposed) {
+    const long total = (long)Co * g.Kp;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int o = (int)(i / g.Kp), k = (int)(i - (long)o * g.Kp);
+        float v = 0.f;
+        if (k < g.K) {
+            const int tap = k / g.Ci, c = k - tap * g.Ci, ky = tap / g.kw, kx = tap - ky * g.kw;
+            v = w[(((long)o * g.Ci + c) * g.kh + ky) * g.kw + kx];
+        }
+        out[transposed ? ((long)k * Co + o) : i] = f2bf(v);
+    }
+}
+// grad OIHW fp32 += dW [Co, Kp] (tap-major)
+__global__ void __launch_bounds__(256) weight_grad_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int Co, ConvGeom g) {
+    const long total = (long)Co * g.K;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        // i indexes the OIHW gradient
+        const int kx = (int)(i % g.kw);
+        long t = i / g.kw;
+        const int ky = (int)(t % g.kh);
+        t /= g.kh;
+        const int c = (int)(t % g.Ci), o = (int)(t / g.Ci);
+        grad[i] += dw[(long)o * g.Kp + (ky * g.kw + kx) * g.Ci + c];
+    }
+}
+
+// x fp32 NCHW -> bf16 NHWC (the stem's input)
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B, int C, int H, int W) {
+    const long total = (long)B * H * W * C;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int xx = (int)(t % W);
+        t /= W;
+        const int yy = (int)(t % H), b = (int)(t / H);
+        out[i] = f2bf(x[(((long)b * C + c) * H + yy) * W + xx]);
+    }
+}
+
+// col[m, (ky*kw+kx)*Ci + c] = x[b, oy*s+ky-p, ox*s+kx-p, c] (0 outside the image; columns K..Kp-1 are 0).
+// One thread per (m, tap, 8-channel chunk) when Ci % 8 == 0, per (m, k) otherwise (stem, Ci = 3).
+__global__ void __launch_bounds__(256) im2col_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, ConvGeom g) {
+    const long M = (long)g.B * g.Ho * g.Wo;
+    if (g.Ci % 8 == 0) {
+        const int cpt = g.Ci / 8, chunks = g.Kp / 8;
+        const long total = M * chunks;
+        for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+            const long m = i / chunks;
+            const int ch = (int)(i - m * chunks);
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (ch * 8 < g.K) {
+                const int tap = ch / cpt, c0 = (ch - tap * cpt) * 8, ky = tap / g.kw, kx = tap - ky * g.kw;
+                const int ox = (int)(m % g.Wo);
+                const long t = m / g.Wo;
+                const int oy = (int)(t % g.Ho), b = (int)(t / g.Ho);
+                const int iy = oy * g.stride + ky - g.pad, ix = ox * g.stride + kx - g.pad;
+                if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W)
+                    v = *reinterpret_cast<const u32x4*>(x + (((long)b * g.H + iy) * g.W + ix) * g.Ci + c0);
+            }
+            *reinterpret_cast<u32x4*>(col + m * g.Kp + (long)ch * 8) = v;
+        }
+    } else {
+        const long total = M * g.Kp;
+        for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+            const long m = i / g.Kp;
+            const int k = (int)(i - m * g.Kp);
+            bf16_t v = 0;
+            if (k < g.K) {
+                const int tap = k / g.Ci, c = k - tap * g.Ci, ky = tap / g.kw, kx = tap - ky * g.kw;
+                const int ox = (int)(m % g.Wo);
+                const long t = m / g.Wo;
+                const int oy = (int)(t % g.Ho), b = (int)(t / g.Ho);
+                const int iy = oy * g.stride + ky - g.pad, ix = ox * g.stride + kx - g.pad;
+                if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) v = x[(((long)b * g.H + iy) * g.W + ix) * g.Ci + c];
+            }
+            col[i] = v;
+        }
+    }
+}
+
+// dx[b,iy,ix,c] (+)= sum over taps with (iy + p - ky) % s == 0 of dcol[(b,oy,ox), tap*Ci + c]   (Ci % 8 == 0)
+__global__ void __launch_bounds__(256) col2im_kernel(const bf16_t* __restrict__ dcol, bf16_t* dx, ConvGeom g, int accumulate) {
+    const int cpt = g.Ci / 8;
+    const long total = (long)g.B * g.H * g.W * cpt;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int c0 = (int)(i % cpt) * 8;
+        long t = i / cpt;
+        const int ix = (int)(t % g.W);
+        t /= g.W;
+        const int iy = (int)(t % g.H), b = (int)(t / g.H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ky = 0; ky < g.kh; ++ky) {
+            const int ny = iy + g.pad - ky;
+            if (ny < 0 || ny % g.stride) continue;
+            const int oy = ny / g.stride;
+            if (oy >= g.Ho) continue;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                const int nx = ix + g.pad - kx;
+                if (nx < 0 || nx % g.stride) continue;
+                const int ox = nx / g.stride;
+                if (ox >= g.Wo) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dcol + (((long)b * g.Ho + oy) * g.Wo + ox) * g.Kp + (ky * g.kw + kx) * g.Ci + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += bf2f((bf16_t)v[j]);
+            }
+        }
+        bf16_t* dst = dx + (((long)b * g.H + iy) * g.W + ix) * g.Ci + c0;
+        if (accumulate) {
+            const bf16x8 o = *reinterpret_cast<const bf16x8*>(dst);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += bf2f((bf16_t)o[j]);
+        }
+        *reinterpret_cast<u32x4*>(dst) = u32x4{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
+    }
+}
+
+// ---- BatchNorm (train mode) over [M, C] bf16, C % 8 == 0 ------------------------------------------------
+// sums[0..C) += sum_m x, sums[C..2C) += sum_m x^2 ; grid (ceil(C/256), row_splits), LDS 2*8*256 floats
+__global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums, long M, int C) {
+    const int tx = TIC_TID & 31, ty = TIC_TID >> 5;
+    const int c0 = TIC_BID_X * 256 + tx * 8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < C) {
+        for (long m = (long)TIC_BID_Y * 8 + ty; m < M; m += (long)TIC_NBLK_Y * 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + m * C + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = bf2f((bf16_t)v[j]);
+                s[j] += f;
+                q[j] += f * f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lds_stf((uint32_t)(ty * 256 + tx * 8 + j) * 4u, s[j]);
+        lds_stf((uint32_t)(2048 + ty * 256 + tx * 8 + j) * 4u, q[j]);
+    }
+    block_sync();
+    const int c = TIC_BID_X * 256 + TIC_TID;
+    if (c < C) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a += lds_ldf((uint32_t)(k * 256 + TIC_TID) * 4u);
+            b += lds_ldf((uint32_t)(2048 + k * 256 + TIC_TID) * 4u);
+        }
+        atomic_addf(sums + c, a);
+        atomic_addf(sums + C + c, b);
+    }
+}
+// train: mean/rstd from the batch sums, running stats updated (unbiased var), counter += 1; eval: from running stats
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd,
+                                                           float* running_mean, float* running_var, long long* num_batches, long M, int C,
+                                                           float eps, float momentum, int train) {
+    const int c = TIC_BID_X * 256 + TIC_TID;
+    if (c < C) {
+        if (train) {
+            const float mu = sums[c] / (float)M;
+            float var = sums[C + c] / (float)M - mu * mu;
+            if (var < 0.f) var = 0.f;
+            mean[c] = mu;
+            rstd[c] = 1.0f / sqrtf(var + eps);
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
+        } else {
+            mean[c] = running_mean[c];
+            rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+        }
+    }
+    if (train && num_batches && c == 0) *num_batches += 1;
+}
+// y = [relu]( (x - mean) rstd gamma + beta [+ identity] )
+__global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, const bf16_t* identity,
+                                                        bf16_t* __restrict__ y, long M, int C, int relu) {
+    const int cpr = C / 8;
+    const long total = M * cpr;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int c0 = (int)(i % cpr) * 8;
+        const long off = (i / cpr) * C + c0;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + off);
+        bf16x8 idv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (identity) idv = *reinterpret_cast<const bf16x8*>(identity + off);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (bf2f((bf16_t)v[j]) - mean[c0 + j]) * rstd[c0 + j] * gamma[c0 + j] + beta[c0 + j];
+            if (identity) f += bf2f((bf16_t)idv[j]);
+            o[j] = (relu && f < 0.f) ? 0.f : f;
+        }
+        *reinterpret_cast<u32x4*>(y + off) = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+    }
+}
+// dz = dy * [y > 0] (if y given);  red[0..C) += sum dz ; red[C..2C) += sum dz * xhat
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, const bf16_t* y, const bf16_t* __restrict__ x,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ red, long M, int C) {
+    const int tx = TIC_TID & 31, ty = TIC_TID >> 5;
+    const int c0 = TIC_BID_X * 256 + tx * 8;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c0 < C) {
+        float mu[8], rs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mu[j] = mean[c0 + j];
+            rs[j] = rstd[c0 + j];
+        }
+        for (long m = (long)TIC_BID_Y * 8 + ty; m < M; m += (long)TIC_NBLK_Y * 8) {
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + m * C + c0);
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + m * C + c0);
+            bf16x8 yv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (y) yv = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float dz = bf2f((bf16_t)d[j]);
+                if (y && !(bf2f((bf16_t)yv[j]) > 0.f)) dz = 0.f;
+                s[j] += dz;
+                q[j] += dz * (bf2f((bf16_t)xv[j]) - mu[j]) * rs[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lds_stf((uint32_t)(ty * 256 + tx * 8 + j) * 4u, s[j]);
+        lds_stf((uint32_t)(2048 + ty * 256 + tx * 8 + j) * 4u, q[j]);
+    }
+    block_sync();
+    const int c = TIC_BID_X * 256 + TIC_TID;
+    if (c < C) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a += lds_ldf((uint32_t)(k * 256 + TIC_TID) * 4u);
+            b += lds_ldf((uint32_t)(2048 + k * 256 + TIC_TID) * 4u);
+        }
+        atomic_addf(red + c, a);
+        atomic_addf(red + C + c, b);
+    }
+}
+// dx = gamma rstd (dz - dbeta/M - xhat dgamma/M);  dskip (optional) (+)= dz  (the identity-path gradient)
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* y, const bf16_t* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ red, bf16_t* __restrict__ dx, bf16_t* dskip, int skip_accumulate, long M, int C) {
+    const int cpr = C / 8;
+    const long total = M * cpr;
+    const float invM = 1.0f / (float)M;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int c0 = (int)(i % cpr) * 8;
+        const long off = (i / cpr) * C + c0;
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + off);
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + off);
+        bf16x8 yv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (y) yv = *reinterpret_cast<const bf16x8*>(y + off);
+        float o[8], z[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float dz = bf2f((bf16_t)d[j]);
+            if (y && !(bf2f((bf16_t)yv[j]) > 0.f)) dz = 0.f;
+            const float xh = (bf2f((bf16_t)xv[j]) - mean[c0 + j]) * rstd[c0 + j];
+            o[j] = gamma[c0 + j] * rstd[c0 + j] * (dz - red[c0 + j] * invM - xh * red[C + c0 + j] * invM);
+            z[j] = dz;
+        }
+        *reinterpret_cast<u32x4*>(dx + off) = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+        if (dskip) {
+            if (skip_accumulate) {
+                const bf16x8 p = *reinterpret_cast<const bf16x8*>(dskip + off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] += bf2f((bf16_t)p[j]);
+            }
+            *reinterpret_cast<u32x4*>(dskip + off) = u32x4{pack2bf(z[0], z[1]), pack2bf(z[2], z[3]), pack2bf(z[4], z[5]), pack2bf(z[6], z[7])};
+        }
+    }
+}
+
+// ---- pools (NHWC bf16, C % 8 == 0) -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+    const int cpr = C / 8;
+    const long total = (long)B * Ho * Wo * cpr;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int c0 = (int)(i % cpr) * 8;
+        long t = i / cpr;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho), b = (int)(t / Ho);
+        float mx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx[j] = -__builtin_huge_valf();
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((long)b * H + iy) * W + ix) * C + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx[j] = fmaxf(mx[j], bf2f((bf16_t)v[j]));
+            }
+        }
+        *reinterpret_cast<u32x4*>(y + (((long)b * Ho + oy) * Wo + ox) * C + c0) =
+            u32x4{pack2bf(mx[0], mx[1]), pack2bf(mx[2], mx[3]), pack2bf(mx[4], mx[5]), pack2bf(mx[6], mx[7])};
+    }
+}
+// gather form: an input pixel receives dy of every window whose FIRST maximum (scan order) it is
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
+                                                           bf16_t* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+    const long total = (long)B * H * W * C;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H), b = (int)(t / H);
+        const bf16_t xv = x[i];
+        float acc = 0.f;
+        for (int oy = (iy - 1 + 1) / 2; oy <= (iy + 1) / 2 && oy < Ho; ++oy) {
+            if (oy < 0) continue;
+            for (int ox = (ix - 1 + 1) / 2; ox <= (ix + 1) / 2 && ox < Wo; ++ox) {
+                if (ox < 0) continue;
+                const long oo = (((long)b * Ho + oy) * Wo + ox) * C + c;
+                if (y[oo] != xv) continue;
+                // is (iy, ix) the first position of this window holding the maximum?
+                bool first = true;
+                for (int ky = 0; ky < 3 && first; ++ky) {
+                    const int yy = oy * 2 + ky - 1;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = ox * 2 + kx - 1;
+                        if (xx < 0 || xx >= W) continue;
+                        if (yy == iy && xx == ix) { ky = 3; break; }
+                        if (x[(((long)b * H + yy) * W + xx) * C + c] == xv) { first = false; break; }
+                    }
+                }
+                if (first) acc += bf2f(dy[oo]);
+            }
+        }
+        dx[i] = f2bf(acc);
+    }
+}
+// [B, HW, C] -> [B, C] mean ; backward broadcast / HW
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int HW, int C) {
+    const int i = TIC_BID_X * 256 + TIC_TID;
+    if (i < B * C) {
+        const int b = i / C, c = i - b * C;
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += bf2f(x[((long)b * HW + p) * C + c]);
+        y[i] = f2bf(s / (float)HW);
+    }
+}
+__global__ void __launch_bounds__(256) avgpool_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int HW, int C) {
+    const long total = (long)B * HW * C;
+    const float inv = 1.0f / (float)HW;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int c = (int)(i % C), b = (int)(i / ((long)HW * C));
+        dx[i] = f2bf(bf2f(dy[(long)b * C + c]) * inv);
+    }
+}
+__global__ void __launch_bounds__(256) add_bf16_kernel(bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long n8) {
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < n8; i += (long)TIC_NBLK_X * 256) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(a + i * 8), y = *reinterpret_cast<const bf16x8*>(b + i * 8);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = bf2f((bf16_t)x[j]) + bf2f((bf16_t)y[j]);
+        *reinterpret_cast<u32x4*>(a + i * 8) = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+    }
+}

@@ -64,7 +64,7 @@ TIC_DEV EpiExtra epi_fetch(const GemmNtParams& p, int m, int n) {
     EpiExtra e;
     e.f = f32x4{0.f, 0.f, 0.f, 0.f};
     e.u = u32x2{0u, 0u};
-    if (m < p.M) {
+    if (m < p.M && n < p.N) {
         if (EPI == TIC_EPI_RESID) e.f = *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.N + n);
         if (EPI == TIC_EPI_DGELU) e.u = *reinterpret_cast<const u32x2*>(p.aux + (size_t)m * p.N + n);
         if (EPI == TIC_EPI_PATCH) e.f = *reinterpret_cast<const f32x4*>(p.rowtab + (size_t)(1 + m % p.patches) * p.N + n);
@@ -73,7 +73,7 @@ TIC_DEV EpiExtra epi_fetch(const GemmNtParams& p, int m, int n) {
 }
 template <int EPI>
 TIC_DEV void epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias, EpiExtra e) {
-    if (m >= p.M) return;
+    if (m >= p.M || n >= p.N) return;   // ragged M; N not a multiple of the tile (conv channels 64, C*k*k ...)
     if (EPI != TIC_EPI_DGELU) v += bias;
     const size_t o = (size_t)m * p.N + n;
     if (EPI == TIC_EPI_BF16) {
@@ -113,7 +113,7 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
     f32x4 bias[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
-        bias[g] = (EPI != TIC_EPI_DGELU && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + col_of(g)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bias[g] = (EPI != TIC_EPI_DGELU && p.bias && col_of(g) < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col_of(g)) : f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_PATCH);
     EpiExtra ex[2][NG];
     if (HAS_EXTRA) {
@@ -141,7 +141,7 @@ template <int EPI>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wm = w >> 1, wn = w & 1;
-    const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = p.N / GEMM_BN;
+    const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;   // B rows >= N read 0
     int tm, tn;
     tile_coords(TIC_BID_X, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
@@ -239,7 +239,7 @@ TIC_DEV uint32_t swz256(uint32_t row) { return (row & 3u) << 2; }
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wn = w >> 1, wk = w & 1;
-    const int tiles_n = p.N / 128, tiles_k = p.K / 128;
+    const int tiles_n = (p.N + 127) / 128, tiles_k = (p.K + 127) / 128;
     int tnn, tkk;
     tile_coords(TIC_BID_X, tiles_n * tiles_k, tiles_n, tiles_k, tnn, tkk);
     const int n0 = tnn * 128, k0 = tkk * 128;
@@ -256,9 +256,12 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
     // staging: a 1-KiB DMA piece = 4 rows x 256 B; piece c = i*4 + w covers tile rows 4c..4c+3;
     // lane -> (row l>>4, physical chunk l&15); source chunk = phys ^ swz256(row)
     uint32_t voa[4], vob[4];
+    bool a_ok, b_ok;
     {
         const uint32_t rr = (uint32_t)l >> 4;                    // row within piece == row & 3
         const uint32_t ch_log = ((uint32_t)l & 15u) ^ (rr << 2);
+        a_ok = (n0 + (int)ch_log * 8) < p.N;                     // columns past N / K (ragged tiles) are zero-filled
+        b_ok = (k0 + (int)ch_log * 8) < p.K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = (i * 4 + w) * 4 + (int)rr;
@@ -272,8 +275,8 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
         const uint32_t base = (uint32_t)buf * GEMM_STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            glds16(ra, base + (uint32_t)(i * 4 + w) * 1024u, voa[i], 0);
-            glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, vob[i], 0);
+            glds16(ra, base + (uint32_t)(i * 4 + w) * 1024u, a_ok ? voa[i] : 0xFFFFFFF0u, 0);
+            glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, b_ok ? vob[i] : 0xFFFFFFF0u, 0);
             voa[i] += strideA;
             vob[i] += strideB;
         }
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-                atomic_addf(p.C + (size_t)n * p.K + kk, acc[nt][kt][r]);
+                if (n < p.N && kk < p.K) atomic_addf(p.C + (size_t)n * p.K + kk, acc[nt][kt][r]);
             }
         }
 }

@@ -10,6 +10,7 @@
 #include "../../include/tic_hip.h"
 #include "attention.h"
 #include "aug.h"
+#include "conv.h"
 #include "elementwise.h"
 #include "gemm.h"
 #include "gemm256.h"
@@ -59,8 +60,8 @@ extern "C" int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
                                 void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
                                 const void* aux_bf16, const float* rowtab, int patches, tic_stream_t stream) {
     TIC_REQUIRE(A && B, "gemm_nt: null operand");
-    TIC_REQUIRE(M >= 1 && N >= 128 && K >= 64, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
-    TIC_REQUIRE(N % 128 == 0 && K % 64 == 0, "gemm_nt: need N %% 128 == 0 and K %% 64 == 0 (N=%d K=%d)", N, K);
+    TIC_REQUIRE(M >= 1 && N >= 8 && K >= 64, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
+    TIC_REQUIRE(N % 8 == 0 && K % 64 == 0, "gemm_nt: need N %% 8 == 0 and K %% 64 == 0 (N=%d K=%d)", N, K);
     TIC_REQUIRE(TIC_ALIGNED16(A) && TIC_ALIGNED16(B), "gemm_nt: operands must be 16-byte aligned");
     const long tiles_m = (M + 127) / 128;
     TIC_REQUIRE(((double)tiles_m * 128.0 + 128.0) * K * 2.0 < 4294967296.0 && (double)N * K * 2.0 < 4294967296.0,
@@ -72,7 +73,7 @@ extern "C" int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches;
     // big products go to the deep-pipelined 256x256 kernel (one block per CU), the rest to the 128x128 one
     const bool big = (N % 256 == 0) && (g_opt_gemm_tile == 256 || (g_opt_gemm_tile == 0 && (long)M * N >= (long)2048 * 1024));
-    const int grid = big ? (int)(((M + 255) / 256) * (N / 256)) : (int)(tiles_m * (N / 128));
+    const int grid = big ? (int)(((M + 255) / 256) * (N / 256)) : (int)(tiles_m * ((N + 127) / 128));
 #define TIC_GEMM_NT_LAUNCH(E)                                                                        \
     do {                                                                                             \
         if (big) {                                                                                   \
@@ -113,10 +114,10 @@ extern "C" int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
 
 extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, tic_stream_t stream) {
     TIC_REQUIRE(A && B && C, "gemm_tn: null operand");
-    TIC_REQUIRE(M >= 1 && N % 128 == 0 && K % 128 == 0 && N >= 128 && K >= 128, "gemm_tn: need N, K multiples of 128 (M=%d N=%d K=%d)", M, N, K);
+    TIC_REQUIRE(M >= 1 && N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8, "gemm_tn: need N, K multiples of 8 (M=%d N=%d K=%d)", M, N, K);
     TIC_REQUIRE(TIC_ALIGNED16(A) && TIC_ALIGNED16(B), "gemm_tn: operands must be 16-byte aligned");
     TIC_REQUIRE(((double)M + 64.0) * (N > K ? N : K) * 2.0 < 4294967296.0, "gemm_tn: operand exceeds the 4 GiB buffer-resource range");
-    const int tiles = (N / 128) * (K / 128);
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     // split the M reduction so that ~4 workgroups per CU are in flight (256 CUs)
     int split = (1024 + tiles - 1) / tiles;
     const int max_split = (M + 63) / 64;
@@ -140,7 +141,7 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
     int tiles = 0;
     for (int g = 0; g < nprob; ++g) {
         TIC_REQUIRE(A[g] && B[g] && C[g] && TIC_ALIGNED16(A[g]) && TIC_ALIGNED16(B[g]), "gemm_tn_group: null / misaligned operand %d", g);
-        TIC_REQUIRE(N[g] % 128 == 0 && K[g] % 128 == 0 && N[g] >= 128 && K[g] >= 128, "gemm_tn_group: need N, K multiples of 128 (problem %d: N=%d K=%d)", g, N[g], K[g]);
+        TIC_REQUIRE(N[g] % 8 == 0 && K[g] % 8 == 0 && N[g] >= 8 && K[g] >= 8, "gemm_tn_group: need N, K multiples of 8 (problem %d: N=%d K=%d)", g, N[g], K[g]);
         TIC_REQUIRE(((double)M + 64.0) * (N[g] > K[g] ? N[g] : K[g]) * 2.0 < 4294967296.0, "gemm_tn_group: operand exceeds the 4 GiB buffer-resource range");
         if (N[g] % 256 || K[g] % 256) ok256 = false;
         tiles += (N[g] / 256) * (K[g] / 256);
@@ -325,6 +326,118 @@ extern "C" int tic_mix_labels(const int64_t* y, float* out, int B, int ncls, flo
     TIC_REQUIRE(y && out && B >= 1 && ncls >= 1, "mix_labels: bad argument");
     TIC_LAUNCH(mix_labels_kernel, (B * ncls + 255) / 256, 256, 0, stream, (const long long*)y, out, B, ncls, lam);
     return tic_after_launch("mix_labels");
+}
+
+// ---- ResNet conv path ----------------------------------------------------------------------------------
+static int conv_geom(ConvGeom& g, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad) {
+    TIC_REQUIRE(B >= 1 && H >= 1 && W >= 1 && Ci >= 1 && kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "conv: bad geometry");
+    g.B = B; g.H = H; g.W = W; g.Ci = Ci; g.kh = kh; g.kw = kw; g.stride = stride; g.pad = pad;
+    g.Ho = (H + 2 * pad - kh) / stride + 1;
+    g.Wo = (W + 2 * pad - kw) / stride + 1;
+    TIC_REQUIRE(g.Ho >= 1 && g.Wo >= 1, "conv: empty output");
+    g.K = kh * kw * Ci;
+    g.Kp = (g.K + 63) / 64 * 64;
+    return TIC_OK;
+}
+extern "C" int tic_conv_weight_pack(const float* w_oihw, void* w16, int Co, int Ci, int kh, int kw, int transposed, tic_stream_t stream) {
+    TIC_REQUIRE(w_oihw && w16 && Co >= 1, "conv_weight_pack: bad argument");
+    ConvGeom g;
+    TIC_TRY(conv_geom(g, 1, kh, kw, Ci, kh, kw, 1, 0));
+    TIC_LAUNCH(weight_ohwi_kernel, ew_grid((long)Co * g.Kp), 256, 0, stream, w_oihw, (bf16_t*)w16, Co, g, transposed);
+    return tic_after_launch("conv_weight_pack");
+}
+extern "C" int tic_conv_weight_grad(const float* dw, float* grad_oihw, int Co, int Ci, int kh, int kw, tic_stream_t stream) {
+    TIC_REQUIRE(dw && grad_oihw && Co >= 1, "conv_weight_grad: bad argument");
+    ConvGeom g;
+    TIC_TRY(conv_geom(g, 1, kh, kw, Ci, kh, kw, 1, 0));
+    TIC_LAUNCH(weight_grad_oihw_kernel, ew_grid((long)Co * g.K), 256, 0, stream, dw, grad_oihw, Co, g);
+    return tic_after_launch("conv_weight_grad");
+}
+extern "C" int tic_nchw_to_nhwc_bf16(const float* x, void* out, int B, int C, int H, int W, tic_stream_t stream) {
+    TIC_REQUIRE(x && out && B >= 1 && C >= 1, "nchw_to_nhwc: bad argument");
+    TIC_LAUNCH(nchw_to_nhwc_kernel, ew_grid((long)B * C * H * W), 256, 0, stream, x, (bf16_t*)out, B, C, H, W);
+    return tic_after_launch("nchw_to_nhwc");
+}
+extern "C" int tic_im2col_bf16(const void* x, void* col, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, tic_stream_t stream) {
+    TIC_REQUIRE(x && col, "im2col: null pointer");
+    ConvGeom g;
+    TIC_TRY(conv_geom(g, B, H, W, Ci, kh, kw, stride, pad));
+    const long M = (long)B * g.Ho * g.Wo;
+    TIC_LAUNCH(im2col_kernel, ew_grid(Ci % 8 == 0 ? M * (g.Kp / 8) : M * g.Kp), 256, 0, stream, (const bf16_t*)x, (bf16_t*)col, g);
+    return tic_after_launch("im2col");
+}
+extern "C" int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, int accumulate,
+                               tic_stream_t stream) {
+    TIC_REQUIRE(dcol && dx && Ci % 8 == 0, "col2im: need Ci %% 8 == 0");
+    ConvGeom g;
+    TIC_TRY(conv_geom(g, B, H, W, Ci, kh, kw, stride, pad));
+    TIC_LAUNCH(col2im_kernel, ew_grid((long)B * H * W * (Ci / 8)), 256, 0, stream, (const bf16_t*)dcol, (bf16_t*)dx, g, accumulate);
+    return tic_after_launch("col2im");
+}
+static int bn_rows(long M) {
+    long r = (M + 63) / 64;
+    return (int)(r > 128 ? 128 : (r < 1 ? 1 : r));
+}
+extern "C" int tic_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 int64_t* num_batches, float* mean, float* rstd, float* scratch2c, const void* identity, void* y, long M, int C,
+                                 float eps, float momentum, int train, int relu, tic_stream_t stream) {
+    TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && scratch2c && y, "batchnorm_fwd: null pointer");
+    TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0, "batchnorm_fwd: need C %% 8 == 0");
+    if (train) {
+        TIC_RT_MEMSET(scratch2c, 0, (size_t)2 * C * 4, stream);
+        TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, scratch2c, M, C);
+    }
+    TIC_LAUNCH(bn_finalize_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, mean, rstd, running_mean, running_var, (long long*)num_batches, M, C, eps,
+               momentum, train);
+    TIC_LAUNCH(bn_apply_kernel, ew_grid(M * (C / 8)), 256, 0, stream, (const bf16_t*)x, mean, rstd, gamma, beta, (const bf16_t*)identity, (bf16_t*)y, M, C, relu);
+    return tic_after_launch("batchnorm_fwd");
+}
+__global__ void __launch_bounds__(256) bn_param_grad_kernel(const float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+    const int c = TIC_BID_X * 256 + TIC_TID;
+    if (c < C) {
+        dbeta[c] += red[c];
+        dgamma[c] += red[C + c];
+    }
+}
+extern "C" int tic_batchnorm_bwd(const void* dy, const void* y_or_null, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                 float* scratch2c, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M, int C,
+                                 tic_stream_t stream) {
+    TIC_REQUIRE(dy && x && mean && rstd && gamma && scratch2c && dx && dgamma && dbeta, "batchnorm_bwd: null pointer");
+    TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0, "batchnorm_bwd: need C %% 8 == 0");
+    TIC_RT_MEMSET(scratch2c, 0, (size_t)2 * C * 4, stream);
+    TIC_LAUNCH(bn_bwd_reduce_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null,
+               (const bf16_t*)x, mean, rstd, scratch2c, M, C);
+    TIC_LAUNCH(bn_bwd_apply_kernel, ew_grid(M * (C / 8)), 256, 0, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null, (const bf16_t*)x, mean, rstd, gamma,
+               scratch2c, (bf16_t*)dx, (bf16_t*)dskip, skip_accumulate, M, C);
+    TIC_LAUNCH(bn_param_grad_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, dgamma, dbeta, C);
+    return tic_after_launch("batchnorm_bwd");
+}
+extern "C" int tic_maxpool3x3s2_fwd(const void* x, void* y, int B, int H, int W, int C, tic_stream_t stream) {
+    TIC_REQUIRE(x && y && C % 8 == 0, "maxpool_fwd: need C %% 8 == 0");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    TIC_LAUNCH(maxpool_fwd_kernel, ew_grid((long)B * Ho * Wo * (C / 8)), 256, 0, stream, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
+    return tic_after_launch("maxpool_fwd");
+}
+extern "C" int tic_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, tic_stream_t stream) {
+    TIC_REQUIRE(x && y && dy && dx, "maxpool_bwd: null pointer");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    TIC_LAUNCH(maxpool_bwd_kernel, ew_grid((long)B * H * W * C), 256, 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, Ho, Wo);
+    return tic_after_launch("maxpool_bwd");
+}
+extern "C" int tic_avgpool_fwd(const void* x, void* y, int B, int HW, int C, tic_stream_t stream) {
+    TIC_REQUIRE(x && y && B >= 1 && HW >= 1, "avgpool_fwd: bad argument");
+    TIC_LAUNCH(avgpool_fwd_kernel, (B * C + 255) / 256, 256, 0, stream, (const bf16_t*)x, (bf16_t*)y, B, HW, C);
+    return tic_after_launch("avgpool_fwd");
+}
+extern "C" int tic_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, tic_stream_t stream) {
+    TIC_REQUIRE(dy && dx && B >= 1 && HW >= 1, "avgpool_bwd: bad argument");
+    TIC_LAUNCH(avgpool_bwd_kernel, ew_grid((long)B * HW * C), 256, 0, stream, (const bf16_t*)dy, (bf16_t*)dx, B, HW, C);
+    return tic_after_launch("avgpool_bwd");
+}
+extern "C" int tic_add_bf16(void* a, const void* b, long n, tic_stream_t stream) {
+    TIC_REQUIRE(a && b && n >= 8 && n % 8 == 0, "add_bf16: need n %% 8 == 0");
+    TIC_LAUNCH(add_bf16_kernel, ew_grid(n / 8), 256, 0, stream, (bf16_t*)a, (const bf16_t*)b, n / 8);
+    return tic_after_launch("add_bf16");
 }
 
 // ---- whole-model layout + phase drivers -------------------------------------------------------------
