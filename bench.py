@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--classes", type=int, default=120)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autograd", action="store_true", help="drive the step through torch autograd + F.cross_entropy (plugin surface) instead of the fused step")
+    ap.add_argument("--aug", action="store_true", help="BASELINE config 3: include the on-GPU augmentation (uint8 256x256 thumbnails -> crop/flip/jitter/gray/erase/normalise) and MixUp/CutMix (soft labels) in every timed step")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -120,6 +121,10 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(B, 3, 224, 224, generator=g).to(dev)
     y = torch.randint(0, C, (B,), generator=g).to(dev)
+    if args.aug:
+        from touhouimageclassification_amd.aug import CutMixOrMixUp, GpuAugment
+        raw = torch.randint(0, 256, (B, 256, 256, 3), dtype=torch.uint8, generator=g).to(dev)   # dataset thumbnails are 256x256
+        augment, mixer = GpuAugment("full", 224, seed=1 + rank), CutMixOrMixUp(C, seed=2 + rank)
 
     def step():
         if args.autograd:
@@ -129,6 +134,9 @@ def main():
             sync.wait()
             opt.step()
             return loss
+        if args.aug:
+            xa, ya = mixer(augment(raw), y)   # parameter sampling on the host, pixels on the GPU
+            return fused_train_step(model, opt, xa, ya, sync)[0]
         return fused_train_step(model, opt, x, y, sync)[0]
 
     if rank == 0:
@@ -188,7 +196,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"ViT-{args.model}/16 224px C={C} fine-tune step (fwd+CE+bwd+AdamW{'+grad all-reduce' if world > 1 else ''})",
                        "per_gpu_batch": B, "global_batch": B * world, "tokens": 197, "parallelism": f"dp{world}",
-                       "optimizer": "AdamW lr=1e-5 wd=0.01 (fused, fp32 master weights)", "step_driver": "autograd" if args.autograd else "fused"},
+                       "optimizer": "AdamW lr=1e-5 wd=0.01 (fused, fp32 master weights)", "step_driver": "autograd" if args.autograd else "fused", "gpu_augmentation": bool(args.aug)},
             "loss": round(loss_v, 5),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,

@@ -38,12 +38,14 @@ struct AttnParams {
 
 // stage one [ATT_ROWS][64] bf16 tile (rows = tokens of image b, columns = col0..col0+63 of a
 // row-major [M, ld] bf16 matrix) into LDS at tile_off; rows >= N are zero-filled (forced
-// out-of-range offset).  28 one-KiB pieces, piece = i*4 + w.
+// out-of-range offset).  28 one-KiB pieces dealt round-robin to the NW waves of the workgroup.
+template <int NW>
 TIC_DEV void att_stage_tile(tic_rsrc_t r, uint32_t tile_off, long row0, int N, int ld, int col0, int l, int w) {
     const uint32_t slot_log = (uint32_t)(l & 7) ^ ((((uint32_t)l >> 4) & 3u) << 1);
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const int piece = i * 4 + w;
+    for (int i = 0; i < (28 + NW - 1) / NW; ++i) {
+        const int piece = i * NW + w;
+        if (piece >= 28) break;   // wave-uniform
         const int row = piece * 8 + (l >> 3);
         const uint32_t voff = (row < N) ? (uint32_t)((((size_t)(row0 + row)) * ld + col0 + slot_log * 8) * 2) : 0xFFFFFFF0u;
         glds16(r, tile_off + (uint32_t)piece * 1024u, voff, 0);
@@ -80,8 +82,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
     const long row0 = (long)b * N;
     const uint32_t KT = 0, VT = ATT_TILE_BYTES;
     const tic_rsrc_t rq = make_rsrc(p.qkv, (uint32_t)((size_t)p.B * N * ld * 2));
-    att_stage_tile(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
-    att_stage_tile(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
+    att_stage_tile<4>(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
+    att_stage_tile<4>(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
     wait_vmcnt0();
     block_sync();
 
@@ -157,7 +159,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
 // LDS: Q | K | V | dO tiles, then lse[224] and delta[224] floats
 #define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4)
 
-__global__ void __launch_bounds__(256, 1) attn_bwd_kernel(AttnParams p) {
+// 8 waves: waves 0-3 run phase A (dK, dV), waves 4-7 run phase B (dQ) CONCURRENTLY -- both only read the LDS tiles and
+// write disjoint outputs, so every SIMD hosts one wave of each phase and their latencies overlap.
+__global__ void __launch_bounds__(512, 2) attn_bwd_kernel(AttnParams p) {
     const int l = lane_id(), w = wave_id(), tid = TIC_TID;
     const int bh = TIC_BID_X, b = bh / p.H, h = bh - b * p.H;
     const int N = p.N, D = p.D, ld = 3 * D;
@@ -166,10 +170,10 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_kernel(AttnParams p) {
     const uint32_t LSE = 4 * ATT_TILE_BYTES, DEL = LSE + ATT_ROWS * 4;
     const tic_rsrc_t rq = make_rsrc(p.qkv, (uint32_t)((size_t)p.B * N * ld * 2));
     const tic_rsrc_t rdo = make_rsrc(p.d_o, (uint32_t)((size_t)p.B * N * D * 2));
-    att_stage_tile(rq, QT, row0, N, ld, h * ATT_HD, l, w);
-    att_stage_tile(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
-    att_stage_tile(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
-    att_stage_tile(rdo, DOT, row0, N, D, h * ATT_HD, l, w);
+    att_stage_tile<8>(rq, QT, row0, N, ld, h * ATT_HD, l, w);
+    att_stage_tile<8>(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
+    att_stage_tile<8>(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
+    att_stage_tile<8>(rdo, DOT, row0, N, D, h * ATT_HD, l, w);
     // delta[q] = sum_d dO[q,d] * O[q,d];  lse (log2 units); padded queries: lse = +inf -> P = 0
     if (tid < ATT_ROWS) {
         float dl = 0.f, ls = __builtin_huge_valf();
@@ -194,7 +198,8 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_kernel(AttnParams p) {
     const int g = l >> 4, li = l & 15;
     const float c = p.scale * 1.4426950408889634f;
 
-    // ---------------- phase A: dK, dV (key on the lane) ----------------
+    // ---------------- phase A: dK, dV (key on the lane) -- waves 0..3 ----------------
+    if (w < 4)
     for (int kt = w; kt < 13; kt += 4) {
         const int key = kt * 16 + li;
         const bool key_ok = key < N;
@@ -210,6 +215,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_kernel(AttnParams p) {
             dva[dt] = f32x4{0, 0, 0, 0};
             dka[dt] = f32x4{0, 0, 0, 0};
         }
+#pragma nounroll
         for (int qp = 0; qp < 7; ++qp) {
             f32x4 pv[2], dsv[2];
 #pragma unroll
@@ -250,8 +256,9 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_kernel(AttnParams p) {
         }
     }
 
-    // ---------------- phase B: dQ (query on the lane) ----------------
-    for (int qb = w; qb < 13; qb += 4) {
+    // ---------------- phase B: dQ (query on the lane) -- waves 4..7 ----------------
+    if (w >= 4)
+    for (int qb = w - 4; qb < 13; qb += 4) {
         const int q = qb * 16 + li;
         bf16x8 fq[2], fd[2];
 #pragma unroll
@@ -263,6 +270,7 @@ __global__ void __launch_bounds__(256, 1) attn_bwd_kernel(AttnParams p) {
         f32x4 dqa[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dqa[dt] = f32x4{0, 0, 0, 0};
+#pragma nounroll
         for (int kp = 0; kp < 7; ++kp) {
             f32x4 dsv[2];
 #pragma unroll
