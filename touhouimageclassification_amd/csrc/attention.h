@@ -159,9 +159,10 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
 // LDS: Q | K | V | dO tiles, then lse[224] and delta[224] floats
 #define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4)
 
-// 8 waves: waves 0-3 run phase A (dK, dV), waves 4-7 run phase B (dQ) CONCURRENTLY -- both only read the LDS tiles and
-// write disjoint outputs, so every SIMD hosts one wave of each phase and their latencies overlap.
-__global__ void __launch_bounds__(512, 2) attn_bwd_kernel(AttnParams p) {
+// 16 waves: waves 0-7 run phase A (dK, dV), waves 8-15 run phase B (dQ) CONCURRENTLY -- both only read the LDS tiles and
+// write disjoint outputs, so every SIMD hosts two waves of each phase and their latencies overlap (the 13 key tiles /
+// 13 query blocks of a head are dealt to 8 waves each: critical path 2 tiles instead of 4).
+__global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     const int l = lane_id(), w = wave_id(), tid = TIC_TID;
     const int bh = TIC_BID_X, b = bh / p.H, h = bh - b * p.H;
     const int N = p.N, D = p.D, ld = 3 * D;
@@ -170,10 +171,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(AttnParams p) {
     const uint32_t LSE = 4 * ATT_TILE_BYTES, DEL = LSE + ATT_ROWS * 4;
     const tic_rsrc_t rq = make_rsrc(p.qkv, (uint32_t)((size_t)p.B * N * ld * 2));
     const tic_rsrc_t rdo = make_rsrc(p.d_o, (uint32_t)((size_t)p.B * N * D * 2));
-    att_stage_tile<8>(rq, QT, row0, N, ld, h * ATT_HD, l, w);
-    att_stage_tile<8>(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
-    att_stage_tile<8>(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
-    att_stage_tile<8>(rdo, DOT, row0, N, D, h * ATT_HD, l, w);
+    att_stage_tile<16>(rq, QT, row0, N, ld, h * ATT_HD, l, w);
+    att_stage_tile<16>(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
+    att_stage_tile<16>(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
+    att_stage_tile<16>(rdo, DOT, row0, N, D, h * ATT_HD, l, w);
     // delta[q] = sum_d dO[q,d] * O[q,d];  lse (log2 units); padded queries: lse = +inf -> P = 0
     if (tid < ATT_ROWS) {
         float dl = 0.f, ls = __builtin_huge_valf();
@@ -198,9 +199,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(AttnParams p) {
     const int g = l >> 4, li = l & 15;
     const float c = p.scale * 1.4426950408889634f;
 
-    // ---------------- phase A: dK, dV (key on the lane) -- waves 0..3 ----------------
-    if (w < 4)
-    for (int kt = w; kt < 13; kt += 4) {
+    // ---------------- phase A: dK, dV (key on the lane) -- waves 0..7 ----------------
+    if (w < 8)
+    for (int kt = w; kt < 13; kt += 8) {
         const int key = kt * 16 + li;
         const bool key_ok = key < N;
         bf16x8 fk[2], fv[2];
@@ -256,9 +257,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_kernel(AttnParams p) {
         }
     }
 
-    // ---------------- phase B: dQ (query on the lane) -- waves 4..7 ----------------
-    if (w >= 4)
-    for (int qb = w - 4; qb < 13; qb += 4) {
+    // ---------------- phase B: dQ (query on the lane) -- waves 8..15 ----------------
+    if (w >= 8)
+    for (int qb = w - 8; qb < 13; qb += 8) {
         const int q = qb * 16 + li;
         bf16x8 fq[2], fd[2];
 #pragma unroll

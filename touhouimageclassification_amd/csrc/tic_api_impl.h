@@ -216,7 +216,7 @@ extern "C" int tic_attention_bwd(const void* qkv, const void* o, const float* ls
     p.qkv = (const bf16_t*)qkv; p.o = (bf16_t*)o; p.lse = (float*)lse; p.d_o = (const bf16_t*)d_o; p.dqkv = (bf16_t*)dqkv;
     p.B = B; p.H = H; p.N = N; p.D = H * 64; p.scale = scale;
     TIC_RT_MAX_LDS(attn_bwd_kernel, ATT_BWD_LDS);
-    TIC_LAUNCH(attn_bwd_kernel, B * H, 512, ATT_BWD_LDS, stream, p);
+    TIC_LAUNCH(attn_bwd_kernel, B * H, 1024, ATT_BWD_LDS, stream, p);
     return tic_after_launch("attention_bwd");
 }
 
