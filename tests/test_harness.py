@@ -135,3 +135,29 @@ def test_ntrain_module_and_trainer(tmp_path):
     # frozen base model (full_finetune=False, ntrain.py:35-37): only the classifier is trainable
     lm2 = ntrain.ViTLModule(10, False, "tiny", lr=1e-3, weight_decay=0.01, full_finetune=False, backend=be)
     assert [n for n, p in lm2.named_parameters() if p.requires_grad] == ["vit.classifier.weight", "vit.classifier.bias"]
+
+
+def test_preprocess_front_end(tmp_path):
+    """ImageFolder front-end: side files, dataset statistics (reference definition), device-side Resize+Normalize"""
+    import numpy as np
+    from PIL import Image
+    from touhouimageclassification_amd.utils import preprocess as pp
+    g = np.random.default_rng(0)
+    for cls in ("alice", "marisa", "reimu"):
+        os.makedirs(tmp_path / cls)
+        for i in range(3):
+            Image.fromarray(g.integers(0, 256, (40, 52, 3), dtype=np.uint8)).save(tmp_path / cls / f"{i}.png")
+    be = SimBackend()
+    ds = pp.get_dataset(str(tmp_path), (32, 32), backend=be)
+    assert ds.classes == ["alice", "marisa", "reimu"] and len(ds) == 9
+    assert pp.get_class_to_idx(str(tmp_path)) == {"alice": 0, "marisa": 1, "reimu": 2}
+    meta = torch.load(tmp_path / pp.META_MEAN_STD_FILENAME, weights_only=False)
+    # reference definition on the same staged thumbnails
+    xs = torch.stack([ds[i][0] for i in range(9)])
+    from touhouimageclassification_amd.aug import GpuAugment
+    r = GpuAugment("none", 32, mean=(0, 0, 0), std=(1, 1, 1), backend=be)(xs).double().view(9, 3, -1)
+    torch.testing.assert_close(meta["mean"], r.mean([0, 2]), atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(meta["std"], r.std([0, 2]), atol=1e-6, rtol=1e-6)
+    y = ds.device_transform(xs[:2])
+    ref = (r[:2].view(2, 3, 32, 32) - meta["mean"].view(1, 3, 1, 1)) / meta["std"].view(1, 3, 1, 1)
+    torch.testing.assert_close(y.double(), ref, atol=1e-5, rtol=1e-5)

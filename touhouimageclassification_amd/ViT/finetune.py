@@ -54,6 +54,16 @@ def _device_of(model) -> torch.device:
     return next(model.parameters()).device
 
 
+def _prepare(model, inputs):
+    """uint8 thumbnails (get_dataset) are resized + normalised on the device by the transform train_model attached"""
+    if inputs.dtype == torch.uint8:
+        tf = getattr(model, "input_transform", None)
+        if tf is None:
+            raise TypeError("uint8 image batch but the model has no input_transform (use utils.preprocess.get_dataset + train_model)")
+        return tf(inputs)
+    return inputs
+
+
 def _logits_of(outputs):
     return outputs.logits if hasattr(outputs, "logits") else outputs   # ViT returns an object, ResNet a tensor
 
@@ -63,8 +73,8 @@ def train_step(model, data, optimizer, criterion, scaler=None, scheduler=None) -
     model.train()
     optimizer.zero_grad()
     dev = _device_of(model)
-    inputs, labels = (t.to(dev, non_blocking=True) for t in data)
-    loss = criterion(_logits_of(model(inputs)), labels)
+    inputs, labels = (torch.as_tensor(t).to(dev, non_blocking=True) for t in data)
+    loss = criterion(_logits_of(model(_prepare(model, inputs))), labels)
     if scaler is not None and getattr(scaler, "is_enabled", lambda: False)():
         scaler.scale(loss).backward()
         scaler.step(optimizer)
@@ -81,8 +91,8 @@ def validate_step(model, data, criterion) -> Tuple[float, int]:
     model.eval()
     dev = _device_of(model)
     with torch.no_grad():
-        inputs, labels = (t.to(dev, non_blocking=True) for t in data)
-        logits = _logits_of(model(inputs))
+        inputs, labels = (torch.as_tensor(t).to(dev, non_blocking=True) for t in data)
+        logits = _logits_of(model(_prepare(model, inputs)))
         loss = criterion(logits, labels)
         correct = (logits.argmax(dim=1) == labels).sum().item()
     return loss.item(), correct
@@ -149,6 +159,8 @@ def train_model(model: torch.nn.Module, dataset, optimizer, scheduler, criterion
     else:
         logger.info("Starting training from scratch.")
 
+    if getattr(dataset, "device_transform", None) is not None:
+        model.input_transform = dataset.device_transform   # Resize + Normalize(dataset stats) as one HIP kernel per batch
     n_val = len(dataset) // val_fraction_denominator
     torch.manual_seed(0)   # split consistency across runs
     train_set, val_set = random_split(dataset, [len(dataset) - n_val, n_val])
