@@ -1,0 +1,51 @@
+"""The CUDA side of the data-parallel path on ONE GPU: a 1-rank RCCL ("nccl") process group with the per-bucket
+collectives forced on exercises exactly the code an N-GPU run executes (side stream, events, all_reduce on slices of
+the flat gradient buffer, optimizer waiting on the side stream) and must leave the step bit-identical to a run
+without it.  The N > 1 arithmetic (SUM of 1/world-scaled gradients == global mean) is covered by tests/test_dp_gloo.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_rccl_bucket_path_is_transparent():
+    from touhouimageclassification_amd.ViT.model import ViT
+    from touhouimageclassification_amd.dist import BucketedGradSync
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from touhouimageclassification_amd.step import fused_train_step
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x = torch.randn(8, 3, 224, 224, device=dev)
+        y = torch.randint(0, 10, (8,), device=dev)
+        results = []
+        for force in (False, True):
+            torch.manual_seed(0)
+            m = ViT(10, pretrained=False, model_name="google/vit-base-patch16-224").to(dev)
+            sync = BucketedGradSync(m, force=force)
+            sync.broadcast_parameters()
+            seen = []
+            if force:
+                inner = m._bucket_hook
+                m.register_bucket_hook(lambda name, gs: (seen.append((name, gs.numel())), inner(name, gs)))
+            opt = FusedAdamW(m, lr=1e-4, weight_decay=0.01)
+            for _ in range(2):
+                loss, _ = fused_train_step(m, opt, x, y, sync)
+            torch.cuda.synchronize()
+            results.append((m._engine.params.clone(), float(loss)))
+            if force:
+                assert [n for n, _ in seen[:14]] == ["head"] + [f"layer{i}" for i in reversed(range(12))] + ["embed"]
+                assert sum(n for _, n in seen[:14]) == m._engine.lay.n_params
+        # atomics in the split-M dW kernels make runs agree to fp32 rounding, not bitwise
+        assert abs(results[0][1] - results[1][1]) < 1e-3
+        assert (results[0][0] - results[1][0]).abs().max().item() < 5e-4
+    finally:
+        dist.destroy_process_group()

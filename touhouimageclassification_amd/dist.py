@@ -16,15 +16,16 @@ import torch.distributed as dist
 
 
 class BucketedGradSync:
-    def __init__(self, model, process_group=None, merge_small_below: int = 1 << 20):
+    def __init__(self, model, process_group=None, force: bool = False):
+        """force=True keeps the per-bucket collectives even at world size 1 (exercises the stream / event path on one GPU)."""
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.cuda = next(model.parameters()).is_cuda
-        self.comm_stream: Optional[torch.cuda.Stream] = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.comm_stream: Optional[torch.cuda.Stream] = torch.cuda.Stream() if (self.cuda and self.active) else None
         self._works: List = []
-        self._pending_small: List[torch.Tensor] = []
-        model.register_bucket_hook(self._on_bucket if self.world > 1 else None)
+        model.register_bucket_hook(self._on_bucket if self.active else None)
 
     @property
     def grad_scale(self) -> float:
@@ -43,7 +44,7 @@ class BucketedGradSync:
 
     def wait(self) -> None:
         """call before optimizer.step(): the compute stream waits for every bucket's all-reduce"""
-        if self.world == 1:
+        if not self.active:
             return
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
@@ -54,6 +55,6 @@ class BucketedGradSync:
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """one-time parameter broadcast at start-up (replicas must start identical)"""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.model._engine.params, src=src, group=self.pg)
             self.model._engine.mark_weights_dirty()
