@@ -48,6 +48,12 @@ int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int epil
                      void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
                      const void* aux_bf16, const float* rowtab, int patches, tic_stream_t stream);
 
+/* same, plus colsum (optional, fp32 [N]) += column sums of the stored output (EPI_BF16 / EPI_DGELU): the bias gradient
+ * of the Linear whose output gradient this GEMM produces, fused into the epilogue */
+int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
+                        void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
+                        const void* aux_bf16, const float* rowtab, int patches, float* colsum, tic_stream_t stream);
+
 /* C[N,K] += A[M,N]^T . B[M,K]  (fp32 accumulate into C; C holds the running gradient).
  * N % 8 == 0, K % 8 == 0.  Replaces the dW half of nn.Linear backward (autograd, finetune.py:62). */
 int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, tic_stream_t stream);
@@ -65,11 +71,20 @@ int tic_layernorm_bwd(const void* dy_bf16, const float* x, long stride, const fl
                       const float* rstd, const float* dres, float* dx, void* dxb_bf16, float* dgamma,
                       float* dbeta, int rows, int D, tic_stream_t stream);
 
+/* + colsum (optional, fp32 [D]) += column sums of dx */
+int tic_layernorm_bwd_ex(const void* dy_bf16, const float* x, long stride, const float* gamma, const float* mean,
+                         const float* rstd, const float* dres, float* dx, void* dxb_bf16, float* dgamma,
+                         float* dbeta, float* colsum, int rows, int D, tic_stream_t stream);
+
 /* softmax(q k^T * scale) v per (image, head); qkv packed [M, 3D], head_dim 64, N <= 208.
  * Replaces F.scaled_dot_product_attention (HF:220-233) and its backward. lse: [B*H, N] fp32. */
 int tic_attention_fwd(const void* qkv, void* o, float* lse, int B, int H, int N, float scale, tic_stream_t stream);
 int tic_attention_bwd(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, int B,
                       int H, int N, float scale, tic_stream_t stream);
+
+/* + dbias (optional, fp32 [3D]) += column sums of dqkv (gradient of the fused q/k/v bias) */
+int tic_attention_bwd_ex(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias, int B,
+                         int H, int N, float scale, tic_stream_t stream);
 
 /* pixel_values [B,C,img,img] fp32 -> patch matrix [B*(img/patch)^2, C*patch*patch] bf16 (HF:60,69) */
 int tic_patchify(const float* x, void* P_bf16, int B, int C, int img, int patch, tic_stream_t stream);

@@ -285,3 +285,47 @@ def check_mix(env):
     lam_adj = 1.0 - (x2 - x1) * (y2 - y1) / float(W * H)
     call("tic_mix_labels", ptr(y), ptr(soft), B, ncls, lam_adj, None)
     torch.testing.assert_close(soft.cpu(), ry_)
+
+
+def check_fused_bias_gradients(env):
+    """column sums fused into producers: GEMM epilogue (BF16 / DGELU), LayerNorm backward, attention backward"""
+    rnd, call, dev = env.rnd, env.call, env.dev
+    # GEMM epilogues, both tile sizes
+    for tile, (M, N, K) in ((128, (150, 192, 64)), (256, (300, 256, 128))):
+        call("tic_set_option", b"gemm_tile", tile, ) if False else None
+        A, B, u = bf(rnd(M, K, scale=0.3)), bf(rnd(N, K, scale=0.3)), bf(rnd(M, N))
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        cs = torch.ones(N, device=dev)
+        env._call("tic_set_option", b"gemm_tile", tile)
+        try:
+            call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), M, N, K, 3, None, ptr(out), None, None, None, ptr(u), None, 0, ptr(cs), None)
+            torch.testing.assert_close(cs, 1 + out.float().sum(0), atol=0.05, rtol=0.02)
+            cs2 = torch.zeros(N, device=dev)
+            bias = rnd(N)
+            call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), M, N, K, 0, ptr(bias), ptr(out), None, None, None, None, None, 0, ptr(cs2), None)
+            torch.testing.assert_close(cs2, out.float().sum(0), atol=0.3, rtol=0.02)
+        finally:
+            env._call("tic_set_option", b"gemm_tile", 0)
+    # LayerNorm backward
+    rows, D = 37, 256
+    x, gamma = rnd(rows, D), 1 + rnd(D, scale=0.1)
+    y = torch.empty(rows, D, dtype=torch.bfloat16, device=dev)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    call("tic_layernorm_fwd", ptr(x), D, ptr(gamma), ptr(gamma), ptr(y), ptr(mean), ptr(rstd), rows, D, 1e-12, None)
+    dy, dres = bf(rnd(rows, D)), rnd(rows, D)
+    dx, dxb = torch.empty(rows, D, device=dev), torch.empty(rows, D, dtype=torch.bfloat16, device=dev)
+    dg, db, cs = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.full((D,), 2.0, device=dev)
+    call("tic_layernorm_bwd_ex", ptr(dy), ptr(x), D, ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dxb), ptr(dg), ptr(db), ptr(cs), rows, D, None)
+    torch.testing.assert_close(cs, 2 + dx.sum(0), atol=1e-4, rtol=1e-4)
+    # attention backward
+    B, H, N = 2, 2, 197
+    Dm = H * 64
+    qkv = bf(rnd(B * N, 3 * Dm))
+    o = torch.empty(B * N, Dm, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B * H, N, device=dev)
+    call("tic_attention_fwd", ptr(qkv), ptr(o), ptr(lse), B, H, N, 0.125, None)
+    do = bf(rnd(B * N, Dm))
+    dqkv = torch.empty_like(qkv)
+    dbias = torch.zeros(3 * Dm, device=dev)
+    call("tic_attention_bwd_ex", ptr(qkv), ptr(o), ptr(lse), ptr(do), ptr(dqkv), ptr(dbias), B, H, N, 0.125, None)
+    torch.testing.assert_close(dbias, dqkv.float().sum(0), atol=0.05, rtol=0.02)

@@ -97,3 +97,7 @@ def test_augment(env, S, H, W):
 
 def test_mix(env):
     kc.check_mix(env)
+
+
+def test_fused_bias_gradients(env):
+    kc.check_fused_bias_gradients(env)

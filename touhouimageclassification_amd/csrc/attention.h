@@ -32,6 +32,7 @@ struct AttnParams {
     float* lse;          // [B*H, N]      (fwd: out, bwd: in)  natural-log-sum-exp of the scaled scores
     const bf16_t* d_o;   // [M, D]        (bwd)
     bf16_t* dqkv;        // [M, 3D]       (bwd out)
+    float* dbias;        // [3D] optional (bwd): += column sums of dqkv = gradient of the fused q/k/v bias
     int B, H, N, D;      // D = H * 64
     float scale;
 };
@@ -246,6 +247,23 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                 dka[dt] = mfma16(att_tr_frag(QT, qp, dt, l), fds, dka[dt]);    // dK^T[d][key]
             }
         }
+        if (p.dbias) {   // padded keys contribute exact zeros (p = 0); reduce over the 16 key lanes
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = dka[dt][r], bsum = dva[dt][r];
+#pragma unroll
+                    for (int msk = 1; msk < 16; msk <<= 1) {
+                        a += shfl_xor(a, msk);
+                        bsum += shfl_xor(bsum, msk);
+                    }
+                    if (li == 0) {
+                        atomic_addf(p.dbias + D + h * ATT_HD + dt * 16 + 4 * g + r, a);
+                        atomic_addf(p.dbias + 2 * D + h * ATT_HD + dt * 16 + 4 * g + r, bsum);
+                    }
+                }
+        }
         if (key_ok) {
             bf16_t* krow = p.dqkv + (size_t)(row0 + key) * ld + D + h * ATT_HD + 4 * g;
             bf16_t* vrow = krow + D;
@@ -294,6 +312,17 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
             const bf16x8 fds = pack8(dsv[0], dsv[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dqa[dt] = mfma16(att_tr_frag(KT, kp, dt, l), fds, dqa[dt]);   // dQ^T[d][q]
+        }
+        if (p.dbias) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = dqa[dt][r];
+#pragma unroll
+                    for (int msk = 1; msk < 16; msk <<= 1) a += shfl_xor(a, msk);
+                    if (li == 0) atomic_addf(p.dbias + h * ATT_HD + dt * 16 + 4 * g + r, a);
+                }
         }
         if (q < N) {
             bf16_t* qrow = p.dqkv + (size_t)(row0 + q) * ld + h * ATT_HD + 4 * g;

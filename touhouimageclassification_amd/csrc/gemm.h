@@ -29,6 +29,7 @@ struct GemmNtParams {
     const bf16_t* aux;       // [M,N] bf16 (DGELU: pre-activation u)
     const float* rowtab;     // [(P+1),N] fp32 (PATCH: position embeddings)
     int patches;             // P (PATCH)
+    float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the consumer), BF16 / DGELU
 };
 
 // 16-byte-chunk XOR swizzle for 128-byte LDS rows: conflict-free for the 16x16x32 row-fragment
@@ -71,13 +72,15 @@ TIC_DEV EpiExtra epi_fetch(const GemmNtParams& p, int m, int n) {
     }
     return e;
 }
+// returns the 4 values written (0 for masked rows / columns) so that callers can form column sums
 template <int EPI>
-TIC_DEV void epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias, EpiExtra e) {
-    if (m >= p.M || n >= p.N) return;   // ragged M; N not a multiple of the tile (conv channels 64, C*k*k ...)
+TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias, EpiExtra e) {
+    if (m >= p.M || n >= p.N) return f32x4{0.f, 0.f, 0.f, 0.f};   // ragged M; N not a multiple of the tile (conv channels 64, C*k*k ...)
     if (EPI != TIC_EPI_DGELU) v += bias;
     const size_t o = (size_t)m * p.N + n;
     if (EPI == TIC_EPI_BF16) {
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        return v;
     } else if (EPI == TIC_EPI_GELU) {
         float u[4], g[4];
 #pragma unroll
@@ -98,6 +101,7 @@ TIC_DEV void epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias,
         const float d0 = bfround(v[0]) * gelu_erf_grad(u0), d1 = bfround(v[1]) * gelu_erf_grad(u1);
         const float d2 = bfround(v[2]) * gelu_erf_grad(u2), d3 = bfround(v[3]) * gelu_erf_grad(u3);
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
+        return f32x4{d0, d1, d2, d3};
     } else if (EPI == TIC_EPI_PATCH) {
         const int img = m / p.patches, pi = m - img * p.patches;
         const size_t orow = (size_t)img * (p.patches + 1) + 1 + pi;
@@ -106,6 +110,7 @@ TIC_DEV void epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias,
         for (int r = 0; r < 4; ++r) y[r] = bfround(v[r]) + e.f[r];
         *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.N + n) = y;
     }
+    return v;
 }
 // NR rows x NG column groups per lane; row_of(r) / col_of(g) give the global coordinates, acc_of(r, g) the value
 template <int EPI, int NR, int NG, class RowF, class ColF, class AccF>
@@ -116,6 +121,9 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
         bias[g] = (EPI != TIC_EPI_DGELU && p.bias && col_of(g) < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col_of(g)) : f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_PATCH);
     EpiExtra ex[2][NG];
+    f32x4 cs[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) cs[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (HAS_EXTRA) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) ex[0][g] = epi_fetch<EPI>(p, row_of(0), col_of(g));
@@ -127,7 +135,26 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
             for (int g = 0; g < NG; ++g) ex[(r + 1) & 1][g] = epi_fetch<EPI>(p, row_of(r + 1), col_of(g));
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) epi_store<EPI>(p, row_of(r), col_of(g), acc_of(r, g), bias[g], ex[r & 1][g]);
+        for (int g = 0; g < NG; ++g) {
+            const f32x4 w4 = epi_store<EPI>(p, row_of(r), col_of(g), acc_of(r, g), bias[g], ex[r & 1][g]);
+            if (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU) cs[g] += w4;
+        }
+    }
+    // fused bias gradient: this lane's rows are summed above; the 16 lanes that share (l>>4) hold the other rows of the
+    // same 4 columns -> butterfly over lane bits 0..3, then one lane per column group adds to the global vector
+    if ((EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU) && p.colsum) {   // kernel-argument condition: wave-uniform
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = cs[g][c];
+                v += shfl_xor(v, 1);
+                v += shfl_xor(v, 2);
+                v += shfl_xor(v, 4);
+                v += shfl_xor(v, 8);
+                if ((lane_id() & 15) == 0 && col_of(g) + c < p.N) atomic_addf(p.colsum + col_of(g) + c, v);
+            }
+        }
     }
 }
 

@@ -83,21 +83,23 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
 
 // dy: bf16 [rows, D] dense.  x / dres / dx / dxb use `stride` elements between rows (dxb: bf16).
 // dx = (dres ? dres : 0) + LN'(dy).  dgamma / dbeta: fp32 [D], accumulated with atomics.
-// LDS: 2 * 4 * D floats.
+// colsum (optional, fp32 [D]) += column sums of dx = the bias gradient of the Linear whose output gradient dx is.
+// LDS: 3 * 4 * D floats.
 template <int NV>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, long stride,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                       const float* __restrict__ rstd_in, const float* dres, float* dx,
                                                       bf16_t* dxb, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      int rows, int D) {
+                                                      float* colsum, int rows, int D) {
     const int l = lane_id(), w = wave_id();
-    f32x4 gm[NV], dg[NV], db[NV];
+    f32x4 gm[NV], dg[NV], db[NV], dc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + l) * 4;
         gm[i] = (c < D) ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0, 0, 0, 0};
         dg[i] = f32x4{0, 0, 0, 0};
         db[i] = f32x4{0, 0, 0, 0};
+        dc[i] = f32x4{0, 0, 0, 0};
     }
     const float invD = 1.0f / (float)D;
     for (int row = TIC_BID_X * 4 + w; row < rows; row += TIC_NBLK_X * 4) {
@@ -138,6 +140,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
                 const long off = (long)row * stride + c;
                 if (dres) o += *reinterpret_cast<const f32x4*>(dres + off);
                 *reinterpret_cast<f32x4*>(dx + off) = o;
+                dc[i] += o;
                 if (dxb) *reinterpret_cast<u32x2*>(dxb + off) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
             }
         }
@@ -149,17 +152,20 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
         if (c < D) {
             lds_stf4((uint32_t)((0 * 4 + w) * D + c) * 4u, dg[i]);
             lds_stf4((uint32_t)((1 * 4 + w) * D + c) * 4u, db[i]);
+            lds_stf4((uint32_t)((2 * 4 + w) * D + c) * 4u, dc[i]);
         }
     }
     block_sync();
     for (int c = TIC_TID; c < D; c += 256) {
-        float a = 0.f, b = 0.f;
+        float a = 0.f, b = 0.f, cc = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
             a += lds_ldf((uint32_t)((0 * 4 + ww) * D + c) * 4u);
             b += lds_ldf((uint32_t)((1 * 4 + ww) * D + c) * 4u);
+            cc += lds_ldf((uint32_t)((2 * 4 + ww) * D + c) * 4u);
         }
         atomic_addf(dgamma + c, a);
         atomic_addf(dbeta + c, b);
+        if (colsum) atomic_addf(colsum + c, cc);
     }
 }

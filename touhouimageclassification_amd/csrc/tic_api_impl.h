@@ -56,10 +56,19 @@ extern "C" int tic_version(void) { return TIC_ABI_VERSION; }
 extern "C" const char* tic_last_error_string(void) { return g_tic_err; }
 
 // ---- GEMM ------------------------------------------------------------------------------------------
+extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
+                                   void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
+                                   const void* aux_bf16, const float* rowtab, int patches, float* colsum, tic_stream_t stream);
 extern "C" int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
                                 void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
                                 const void* aux_bf16, const float* rowtab, int patches, tic_stream_t stream) {
+    return tic_gemm_nt_bf16_ex(A, B, M, N, K, epilogue, bias, out_bf16, out2_bf16, out_f32, resid, aux_bf16, rowtab, patches, nullptr, stream);
+}
+extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
+                                   void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
+                                   const void* aux_bf16, const float* rowtab, int patches, float* colsum, tic_stream_t stream) {
     TIC_REQUIRE(A && B, "gemm_nt: null operand");
+    TIC_REQUIRE(!colsum || epilogue == TIC_EPI_BF16 || epilogue == TIC_EPI_DGELU, "gemm_nt: colsum is available for EPI_BF16 / EPI_DGELU only");
     TIC_REQUIRE(M >= 1 && N >= 8 && K >= 64, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
     TIC_REQUIRE(N % 8 == 0 && K % 64 == 0, "gemm_nt: need N %% 8 == 0 and K %% 64 == 0 (N=%d K=%d)", N, K);
     TIC_REQUIRE(TIC_ALIGNED16(A) && TIC_ALIGNED16(B), "gemm_nt: operands must be 16-byte aligned");
@@ -70,7 +79,7 @@ extern "C" int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     memset(&p, 0, sizeof(p));
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.bias = bias;
     p.out = (bf16_t*)out_bf16; p.out2 = (bf16_t*)out2_bf16; p.out_f32 = out_f32; p.resid = resid;
-    p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches;
+    p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches; p.colsum = colsum;
     // big products go to the deep-pipelined 256x256 kernel (one block per CU), the rest to the 128x128 one
     const bool big = (N % 256 == 0) && (g_opt_gemm_tile == 256 || (g_opt_gemm_tile == 0 && (long)M * N >= (long)2048 * 1024));
     const int grid = big ? (int)(((M + 255) / 256) * (N / 256)) : (int)(tiles_m * ((N + 127) / 128));
@@ -165,6 +174,9 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
 }
 
 // ---- LayerNorm -------------------------------------------------------------------------------------
+extern "C" int tic_layernorm_bwd_ex(const void* dy_bf16, const float* x, long stride, const float* gamma, const float* mean,
+                                    const float* rstd, const float* dres, float* dx, void* dxb_bf16, float* dgamma,
+                                    float* dbeta, float* colsum, int rows, int D, tic_stream_t stream);
 static int ln_grid(int rows) {
     int g = (rows + 3) / 4;
     return g > 2048 ? 2048 : (g < 1 ? 1 : g);
@@ -182,19 +194,26 @@ extern "C" int tic_layernorm_fwd(const float* x, long in_stride, const float* ga
 extern "C" int tic_layernorm_bwd(const void* dy_bf16, const float* x, long stride, const float* gamma, const float* mean,
                                  const float* rstd, const float* dres, float* dx, void* dxb_bf16, float* dgamma,
                                  float* dbeta, int rows, int D, tic_stream_t stream) {
+    return tic_layernorm_bwd_ex(dy_bf16, x, stride, gamma, mean, rstd, dres, dx, dxb_bf16, dgamma, dbeta, nullptr, rows, D, stream);
+}
+extern "C" int tic_layernorm_bwd_ex(const void* dy_bf16, const float* x, long stride, const float* gamma, const float* mean,
+                                    const float* rstd, const float* dres, float* dx, void* dxb_bf16, float* dgamma,
+                                    float* dbeta, float* colsum, int rows, int D, tic_stream_t stream) {
     TIC_REQUIRE(dy_bf16 && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
     TIC_REQUIRE(rows >= 1 && D >= 4 && D % 4 == 0 && D <= 1024 && stride % 4 == 0, "layernorm_bwd: need D %% 4 == 0, D <= 1024 (D=%d)", D);
     const int nv = (D + 255) / 256;
     int grid = ln_grid(rows);
     if (grid > 512) grid = 512;   // fewer, longer blocks: one dgamma/dbeta atomic row per block
-    const size_t lds = (size_t)2 * 4 * D * 4;
-#define TIC_LN_BWD(NV) TIC_LAUNCH(ln_bwd_kernel<NV>, grid, 256, lds, stream, (const bf16_t*)dy_bf16, x, stride, gamma, mean, rstd, dres, dx, (bf16_t*)dxb_bf16, dgamma, dbeta, rows, D)
+    const size_t lds = (size_t)3 * 4 * D * 4;
+#define TIC_LN_BWD(NV) TIC_LAUNCH(ln_bwd_kernel<NV>, grid, 256, lds, stream, (const bf16_t*)dy_bf16, x, stride, gamma, mean, rstd, dres, dx, (bf16_t*)dxb_bf16, dgamma, dbeta, colsum, rows, D)
     if (nv == 1) TIC_LN_BWD(1); else if (nv == 2) TIC_LN_BWD(2); else if (nv == 3) TIC_LN_BWD(3); else TIC_LN_BWD(4);
 #undef TIC_LN_BWD
     return tic_after_launch("layernorm_bwd");
 }
 
 // ---- attention -------------------------------------------------------------------------------------
+extern "C" int tic_attention_bwd_ex(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias,
+                                    int B, int H, int N, float scale, tic_stream_t stream);
 extern "C" int tic_attention_fwd(const void* qkv, void* o, float* lse, int B, int H, int N, float scale, tic_stream_t stream) {
     TIC_REQUIRE(qkv && o && lse, "attention_fwd: null pointer");
     TIC_REQUIRE(B >= 1 && H >= 1 && N >= 1 && N <= 208, "attention_fwd: need 1 <= N <= 208 (N=%d)", N);
@@ -208,12 +227,16 @@ extern "C" int tic_attention_fwd(const void* qkv, void* o, float* lse, int B, in
 }
 extern "C" int tic_attention_bwd(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, int B,
                                  int H, int N, float scale, tic_stream_t stream) {
+    return tic_attention_bwd_ex(qkv, o, lse, d_o, dqkv, nullptr, B, H, N, scale, stream);
+}
+extern "C" int tic_attention_bwd_ex(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias,
+                                    int B, int H, int N, float scale, tic_stream_t stream) {
     TIC_REQUIRE(qkv && o && lse && d_o && dqkv, "attention_bwd: null pointer");
     TIC_REQUIRE(B >= 1 && H >= 1 && N >= 1 && N <= 208, "attention_bwd: need 1 <= N <= 208 (N=%d)", N);
     TIC_REQUIRE((double)B * N * 3 * H * 64 * 2 < 4294967296.0, "attention_bwd: qkv exceeds the 4 GiB buffer-resource range");
     AttnParams p;
     memset(&p, 0, sizeof(p));
-    p.qkv = (const bf16_t*)qkv; p.o = (bf16_t*)o; p.lse = (float*)lse; p.d_o = (const bf16_t*)d_o; p.dqkv = (bf16_t*)dqkv;
+    p.qkv = (const bf16_t*)qkv; p.o = (bf16_t*)o; p.lse = (float*)lse; p.d_o = (const bf16_t*)d_o; p.dqkv = (bf16_t*)dqkv; p.dbias = dbias;
     p.B = B; p.H = H; p.N = N; p.D = H * 64; p.scale = scale;
     TIC_RT_MAX_LDS(attn_bwd_kernel, ATT_BWD_LDS);
     TIC_LAUNCH(attn_bwd_kernel, B * H, 1024, ATT_BWD_LDS, stream, p);
@@ -606,8 +629,9 @@ extern "C" int tic_vit_backward_head(const TicVitState* st, const float* dlogits
     TIC_RT_MEMSET(dh, 0, (size_t)c.M * D * 4, s);
     TIC_RT_MEMSET(c.ws + y.dhb, 0, (size_t)c.M * D * 2, s);
     float* hL = (float*)(c.ws + y.hs + c.L * y.hs_stride);
-    TIC_TRY(tic_layernorm_bwd(c.ws + y.dzf, hL, (long)N * D, c.P + y.lnf_g, (float*)(c.ws + y.meanf), (float*)(c.ws + y.rstdf), nullptr, dh,
-                              c.ws + y.dhb, c.G + y.lnf_g, c.G + y.lnf_b, B, D, s));
+    // the bf16 gradient this emits is dY of the last layer's fc2: its column sums are that layer's b2 gradient
+    TIC_TRY(tic_layernorm_bwd_ex(c.ws + y.dzf, hL, (long)N * D, c.P + y.lnf_g, (float*)(c.ws + y.meanf), (float*)(c.ws + y.rstdf), nullptr, dh,
+                                 c.ws + y.dhb, c.G + y.lnf_g, c.G + y.lnf_b, c.G + y.layer0 + (c.L - 1) * y.layer_stride + y.b2, B, D, s));
     return TIC_OK;
 }
 
@@ -630,12 +654,14 @@ extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stre
     char* dqkv = c.ws + y.dqkv;
     char* dhb2 = c.ws + y.dhb2;
     // dX chain first (MLP, then attention); the four weight gradients of the block go out as ONE grouped launch
-    TIC_TRY(tic_gemm_nt_bf16(dhb, lt + y.t_w2, M, F, D, TIC_EPI_DGELU, nullptr, du, nullptr, nullptr, nullptr, a + y.u, nullptr, 0, s));
+    // bias gradients ride on the producers of each dY: b1 <- DGELU epilogue, bo <- LN2 backward, bqkv <- attention
+    // backward, b2 (of the layer below) <- LN1 backward; b2 of THIS layer was added by the producer of dhb
+    TIC_TRY(tic_gemm_nt_bf16_ex(dhb, lt + y.t_w2, M, F, D, TIC_EPI_DGELU, nullptr, du, nullptr, nullptr, nullptr, a + y.u, nullptr, 0, lg + y.b1, s));
     TIC_TRY(tic_gemm_nt_bf16(du, lt + y.t_w1, M, D, F, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
-    TIC_TRY(tic_layernorm_bwd(da, (float*)(a + y.hmid), D, lp + y.ln2_g, (float*)(a + y.mean2), (float*)(a + y.rstd2), dh, dh, dhb2, lg + y.ln2_g,
-                              lg + y.ln2_b, M, D, s));
+    TIC_TRY(tic_layernorm_bwd_ex(da, (float*)(a + y.hmid), D, lp + y.ln2_g, (float*)(a + y.mean2), (float*)(a + y.rstd2), dh, dh, dhb2, lg + y.ln2_g,
+                                 lg + y.ln2_b, lg + y.bo, M, D, s));
     TIC_TRY(tic_gemm_nt_bf16(dhb2, lt + y.t_wo, M, D, D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
-    TIC_TRY(tic_attention_bwd(a + y.qkv, a + y.o, (float*)(a + y.lse), da, dqkv, B, (int)c.H, N, 0.125f, s));
+    TIC_TRY(tic_attention_bwd_ex(a + y.qkv, a + y.o, (float*)(a + y.lse), da, dqkv, lg + y.bqkv, B, (int)c.H, N, 0.125f, s));
     TIC_TRY(tic_gemm_nt_bf16(dqkv, lt + y.t_wqkv, M, D, 3 * D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
     {
         const void* gA[4] = {dhb, du, dhb2, dqkv};
@@ -644,11 +670,8 @@ extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stre
         const int gN[4] = {D, F, D, 3 * D}, gK[4] = {F, D, D, D};
         TIC_TRY(tic_gemm_tn_group_bf16(4, gA, gB, gC, gN, gK, M, s));
     }
-    TIC_TRY(tic_colsum_bf16(dhb, lg + y.b2, M, D, s));
-    TIC_TRY(tic_colsum_bf16(du, lg + y.b1, M, F, s));
-    TIC_TRY(tic_colsum_bf16(dhb2, lg + y.bo, M, D, s));
-    TIC_TRY(tic_colsum_bf16(dqkv, lg + y.bqkv, M, 3 * D, s));
-    TIC_TRY(tic_layernorm_bwd(da, hin, D, lp + y.ln1_g, (float*)(a + y.mean1), (float*)(a + y.rstd1), dh, dh, dhb, lg + y.ln1_g, lg + y.ln1_b, M, D, s));
+    TIC_TRY(tic_layernorm_bwd_ex(da, hin, D, lp + y.ln1_g, (float*)(a + y.mean1), (float*)(a + y.rstd1), dh, dh, dhb, lg + y.ln1_g, lg + y.ln1_b,
+                                 l > 0 ? c.G + y.layer0 + (l - 1) * y.layer_stride + y.b2 : nullptr, M, D, s));
     return TIC_OK;
 }
 
