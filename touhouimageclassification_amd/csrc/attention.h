@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
 }
 
 // LDS: Q | K | V | dO tiles, then lse[224] and delta[224] floats
-#define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4)
+#define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4 + 3 * ATT_HD * 4)   // + per-block q/k/v bias-gradient sums
 
 // 16 waves: waves 0-7 run phase A (dK, dV), waves 8-15 run phase B (dQ) CONCURRENTLY -- both only read the LDS tiles and
 // write disjoint outputs, so every SIMD hosts two waves of each phase and their latencies overlap (the 13 key tiles /
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     const int N = p.N, D = p.D, ld = 3 * D;
     const long row0 = (long)b * N;
     const uint32_t QT = 0, KT = ATT_TILE_BYTES, VT = 2 * ATT_TILE_BYTES, DOT = 3 * ATT_TILE_BYTES;
-    const uint32_t LSE = 4 * ATT_TILE_BYTES, DEL = LSE + ATT_ROWS * 4;
+    const uint32_t LSE = 4 * ATT_TILE_BYTES, DEL = LSE + ATT_ROWS * 4, DBL = DEL + ATT_ROWS * 4;   // DBL: [3][64] floats
     const tic_rsrc_t rq = make_rsrc(p.qkv, (uint32_t)((size_t)p.B * N * ld * 2));
     const tic_rsrc_t rdo = make_rsrc(p.d_o, (uint32_t)((size_t)p.B * N * D * 2));
     att_stage_tile<16>(rq, QT, row0, N, ld, h * ATT_HD, l, w);
@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
         lds_stf(LSE + 4u * tid, ls);
         lds_stf(DEL + 4u * tid, dl);
     }
+    if (tid < 3 * ATT_HD) lds_stf(DBL + 4u * tid, 0.f);
     wait_vmcnt0();
     block_sync();
 
@@ -201,6 +202,12 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     const float c = p.scale * 1.4426950408889634f;
 
     // ---------------- phase A: dK, dV (key on the lane) -- waves 0..7 ----------------
+    f32x4 bk[4], bv[4];   // per-lane bias-gradient partials summed over this wave's tiles: (dk, dv) in phase A, (dq, -) in phase B
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        bk[dt] = f32x4{0, 0, 0, 0};
+        bv[dt] = f32x4{0, 0, 0, 0};
+    }
     if (w < 8)
     for (int kt = w; kt < 13; kt += 8) {
         const int key = kt * 16 + li;
@@ -247,22 +254,10 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                 dka[dt] = mfma16(att_tr_frag(QT, qp, dt, l), fds, dka[dt]);    // dK^T[d][key]
             }
         }
-        if (p.dbias) {   // padded keys contribute exact zeros (p = 0); reduce over the 16 key lanes
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float a = dka[dt][r], bsum = dva[dt][r];
-#pragma unroll
-                    for (int msk = 1; msk < 16; msk <<= 1) {
-                        a += shfl_xor(a, msk);
-                        bsum += shfl_xor(bsum, msk);
-                    }
-                    if (li == 0) {
-                        atomic_addf(p.dbias + D + h * ATT_HD + dt * 16 + 4 * g + r, a);
-                        atomic_addf(p.dbias + 2 * D + h * ATT_HD + dt * 16 + 4 * g + r, bsum);
-                    }
-                }
+        for (int dt = 0; dt < 4; ++dt) {   // padded keys contribute exact zeros (p = 0)
+            bk[dt] += dka[dt];
+            bv[dt] += dva[dt];
         }
         if (key_ok) {
             bf16_t* krow = p.dqkv + (size_t)(row0 + key) * ld + D + h * ATT_HD + 4 * g;
@@ -313,22 +308,39 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dqa[dt] = mfma16(att_tr_frag(KT, kp, dt, l), fds, dqa[dt]);   // dQ^T[d][q]
         }
-        if (p.dbias) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float a = dqa[dt][r];
-#pragma unroll
-                    for (int msk = 1; msk < 16; msk <<= 1) a += shfl_xor(a, msk);
-                    if (li == 0) atomic_addf(p.dbias + h * ATT_HD + dt * 16 + 4 * g + r, a);
-                }
-        }
+        for (int dt = 0; dt < 4; ++dt) bk[dt] += dqa[dt];
         if (q < N) {
             bf16_t* qrow = p.dqkv + (size_t)(row0 + q) * ld + h * ATT_HD + 4 * g;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
                 *reinterpret_cast<u32x2*>(qrow + dt * 16) = u32x2{pack2bf(dqa[dt][0], dqa[dt][1]), pack2bf(dqa[dt][2], dqa[dt][3])};
         }
+    }
+    // q/k/v bias gradient: lanes (16 rows) -> wave (butterfly) -> workgroup (LDS adds) -> ONE global atomic per column.
+    // Adding per tile straight to global memory put 2 656 workgroups on the same 3D addresses (14x slower atomics).
+    if (p.dbias) {   // kernel argument: uniform
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = bk[dt][r], b2 = bv[dt][r];
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) {
+                    a += shfl_xor(a, msk);
+                    b2 += shfl_xor(b2, msk);
+                }
+                if (li == 0) {
+                    const uint32_t col = (uint32_t)(dt * 16 + 4 * g + r);
+                    if (w < 8) {
+                        lds_addf(DBL + 4u * (64u + col), a);
+                        lds_addf(DBL + 4u * (128u + col), b2);
+                    } else {
+                        lds_addf(DBL + 4u * col, a);
+                    }
+                }
+            }
+        block_sync();
+        if (tid < 3 * ATT_HD) atomic_addf(p.dbias + (tid >> 6) * D + h * ATT_HD + (tid & 63), lds_ldf(DBL + 4u * tid));
     }
 }
