@@ -31,7 +31,7 @@ typedef void* tic_stream_t; /* hipStream_t */
 #define TIC_ABI_VERSION 1
 int tic_version(void);
 const char* tic_last_error_string(void);
-/* process-wide tuning knob for A/B measurements: "gemm_tile" = 0 (auto) | 128 | 256 */
+/* process-wide tuning knobs for A/B measurements: "gemm_tile" = 0 (auto) | 128 | 256 ; "tn_streamk" = 1 | 0 */
 int tic_set_option(const char* name, int value);
 
 /* GEMM epilogues (fused into the MFMA kernel's store) */

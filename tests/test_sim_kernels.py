@@ -74,13 +74,16 @@ def test_gemm_nt256_pipelined(env, M, N, K):
         call("tic_set_option", b"gemm_tile", 0)
 
 
+@pytest.mark.parametrize("streamk", [0, 3, 7])   # 3 / 7 shares: partial tiles, shares crossing tile and problem boundaries
 @pytest.mark.parametrize("M,shapes", [(200, [(256, 256)]), (333, [(256, 512), (512, 256), (256, 256)]), (64, [(128, 256), (256, 256)])])
-def test_gemm_tn_group(env, M, shapes):
+def test_gemm_tn_group(env, M, shapes, streamk):
     call("tic_set_option", b"gemm_tile", 256)
+    call("tic_set_option", b"tn_streamk", streamk)
     try:
         kc.check_gemm_tn_group(env, M, shapes)   # last case has a 128-multiple shape -> per-problem fallback
     finally:
         call("tic_set_option", b"gemm_tile", 0)
+        call("tic_set_option", b"tn_streamk", 1)
 
 
 def test_augment(env):

@@ -27,34 +27,34 @@ struct GemmTnGroupParams {
     int nprob, M, total_tiles;
 };
 
-__global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp) {
-    const int tid = TIC_TID, l = tid & 63, w = wave_id();
-    const int wr = w >> 2, wc = w & 3;
-    // XCD-contiguous tile order, then problem lookup (wave-uniform)
-    int wg;
-    {
-        const int bid = TIC_BID_X, nwg = gp.total_tiles;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
+TIC_DEV void tn_tile_lookup(const GemmTnGroupParams& gp, int tile, const bf16_t*& Ap, const bf16_t*& Bp, float*& Cp, int& N, int& K, int& n0, int& k0) {
     int pi = 0;
 #pragma unroll
     for (int g = 1; g < TN_MAX_GROUP; ++g)
-        if (g < gp.nprob && wg >= gp.prob[g].tile_start) pi = g;
-    const bf16_t* Ap = gp.prob[0].A;
-    const bf16_t* Bp = gp.prob[0].B;
-    float* Cp = gp.prob[0].C;
-    int N = gp.prob[0].N, K = gp.prob[0].K, t0 = 0;
+        if (g < gp.nprob && tile >= gp.prob[g].tile_start) pi = g;
+    Ap = gp.prob[0].A; Bp = gp.prob[0].B; Cp = gp.prob[0].C; N = gp.prob[0].N; K = gp.prob[0].K;
+    int t0 = 0;
 #pragma unroll
     for (int g = 1; g < TN_MAX_GROUP; ++g)
         if (pi == g) {
             Ap = gp.prob[g].A; Bp = gp.prob[g].B; Cp = gp.prob[g].C; N = gp.prob[g].N; K = gp.prob[g].K; t0 = gp.prob[g].tile_start;
         }
-    const int tiles_k = K / 256, lt = wg - t0;
-    const int n0 = (lt / tiles_k) * 256, k0 = (lt % tiles_k) * 256;
-    const int M = gp.M;
-    const tic_rsrc_t ra = make_rsrc(Ap, (uint32_t)((size_t)M * N * 2));
-    const tic_rsrc_t rb = make_rsrc(Bp, (uint32_t)((size_t)M * K * 2));
+    const int tiles_k = K / 256, lt = tile - t0;
+    n0 = (lt / tiles_k) * 256;
+    k0 = (lt % tiles_k) * 256;
+}
+
+// One 256x256 output tile (origin n0, k0 of problem A/B/C) over the M steps [step0, step1) of 64 rows.
+// ATOMIC = false: the workgroup owns the whole reduction, C += acc with plain read-modify-write;
+// ATOMIC = true : partial reduction (stream-K share), C += acc with fp32 atomics (two 128-B row segments / instruction).
+template <bool ATOMIC>
+TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, int N, int K, int M, int n0, int k0, int step0, int step1) {
+    const int tid = TIC_TID, l = tid & 63, w = wave_id();
+    const int wr = w >> 2, wc = w & 3;
+    // rows >= row_end (the end of this segment, or M) are outside the range check and read as 0
+    const int row_end = (step1 * 64 < M) ? step1 * 64 : M;
+    const tic_rsrc_t ra = make_rsrc(Ap, (uint32_t)((size_t)row_end * N * 2));
+    const tic_rsrc_t rb = make_rsrc(Bp, (uint32_t)((size_t)row_end * K * 2));
 
     // ---- LDS-DMA: half-tile = [64 m][128 cols] = 16 pieces of 4 rows; this wave moves pieces 2w, 2w+1.
     // The row advance lives in the VGPR offset (only that offset is range-checked: rows >= M read 0).
@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const uint32_t row = (uint32_t)(2 * w + j) * 4 + rr;
+            const uint32_t row = (uint32_t)step0 * 64u + (uint32_t)(2 * w + j) * 4 + rr;
             voa[h][j] = (uint32_t)(((size_t)row * N + n0 + h * 128 + ch_log * 8) * 2);
             vob[h][j] = (uint32_t)(((size_t)row * K + k0 + h * 128 + ch_log * 8) * 2);
         }
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
     };
 
     // same 5-6-phase-deep schedule as gemm256.h; steps past the end read rows >= M, i.e. zero fills
-    const int nsteps = (M + 63) / 64;
+    const int nsteps = step1 - step0;
     issue(0, 0);
     issue(0, 1);
     issue(0, 2);
@@ -183,7 +183,45 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
                 for (int r = 0; r < 16; ++r) {
                     const int n = n0 + i * 128 + wr * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
                     float* dst = Cp + (size_t)n * K + kk;
-                    *dst = *dst + acc[i][j][nt][r];
+                    if (ATOMIC) atomic_addf(dst, acc[i][j][nt][r]);
+                    else *dst = *dst + acc[i][j][nt][r];
                 }
             }
+}
+
+__global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp) {
+    // XCD-contiguous tile order, then problem lookup (wave-uniform)
+    int wg;
+    {
+        const int bid = TIC_BID_X, nwg = gp.total_tiles;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const bf16_t *Ap, *Bp;
+    float* Cp;
+    int N, K, n0, k0;
+    tn_tile_lookup(gp, wg, Ap, Bp, Cp, N, K, n0, k0);
+    tn256_tile_segment<false>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, (gp.M + 63) / 64);
+}
+
+// Stream-K form: the flattened (tile, M step) space is cut into gridDim.x equal contiguous shares (0.75 tile per CU
+// for a ViT-L block on 256 CUs instead of 192 busy + 64 idle CUs); a share is processed as the 1-2 segments it has
+// inside single tiles, each through the pipelined tile routine (the pipeline restarts once at a tile boundary), and
+// every partial tile is ADDED to C with fp32 atomics.  Flushes of different workgroups fall at different times and
+// overlap the others' MFMA work.
+__global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_kernel(GemmTnGroupParams gp, int nsteps) {
+    const long total_units = (long)gp.total_tiles * nsteps;
+    int u = (int)(total_units * TIC_BID_X / TIC_NBLK_X);
+    const int u1 = (int)(total_units * (TIC_BID_X + 1) / TIC_NBLK_X);
+    while (u < u1) {   // wave-uniform
+        const int tile = u / nsteps, s0 = u - tile * nsteps;
+        int s1 = s0 + (u1 - u);
+        if (s1 > nsteps) s1 = nsteps;
+        const bf16_t *Ap, *Bp;
+        float* Cp;
+        int N, K, n0, k0;
+        tn_tile_lookup(gp, tile, Ap, Bp, Cp, N, K, n0, k0);
+        tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s0, s1);
+        u += s1 - s0;
+    }
 }

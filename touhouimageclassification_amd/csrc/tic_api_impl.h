@@ -42,11 +42,17 @@ static int tic_after_launch(const char* what) {
     return TIC_OK;
 }
 
-// tuning knobs (process-wide, for A/B measurements and tests): "gemm_tile" = 0 (auto) | 128 | 256
+// tuning knobs (process-wide, for A/B measurements and tests): "gemm_tile" = 0 (auto) | 128 | 256 ;
+// "tn_streamk" = 1 (default: grouped dW as 256 equal stream-K shares) | 0 (one workgroup per full-M tile)
 static int g_opt_gemm_tile = 0;
+static int g_opt_tn_streamk = 1;
 extern "C" int tic_set_option(const char* name, int value) {
     if (name && !strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) {
         g_opt_gemm_tile = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "tn_streamk") && value >= 0 && value <= 4096) {   // 0 off, 1 = 256 shares, n > 1 = n shares (tests)
+        g_opt_tn_streamk = value;
         return TIC_OK;
     }
     return tic_fail(TIC_EINVAL, "set_option: unknown option/value %s=%d", name ? name : "(null)", value);
@@ -165,6 +171,13 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
             t += (N[g] / 256) * (K[g] / 256);
         }
         gp.nprob = nprob; gp.M = M; gp.total_tiles = t;
+        const int nsteps = (M + 63) / 64;
+        const long shares = g_opt_tn_streamk == 1 ? 256 : g_opt_tn_streamk;   // one share per CU by default
+        if (g_opt_tn_streamk && (long)t * nsteps >= shares) {
+            TIC_RT_MAX_LDS(gemm_tn256_streamk_kernel, G256_LDS_BYTES);
+            TIC_LAUNCH(gemm_tn256_streamk_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps);
+            return tic_after_launch("gemm_tn_group(stream-K)");
+        }
         TIC_RT_MAX_LDS(gemm_tn256_kernel, G256_LDS_BYTES);
         TIC_LAUNCH(gemm_tn256_kernel, t, 512, G256_LDS_BYTES, stream, gp);
         return tic_after_launch("gemm_tn_group");
