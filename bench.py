@@ -163,29 +163,46 @@ def main():
     if rank == 0:
         print(f"[bench] {args.steps} steps in {dt:.3f}s = {world * B * args.steps / dt:.1f} img/s, loss {loss_v:.4f}", file=sys.stderr, flush=True)
 
-    # dominant kernel on its own: gemm_nt at the fc1 shape [M,D] x [F,D]^T with the GELU epilogue,
-    # HIP events on the stream it is launched on (torch's current stream)
+    # dominant kernel of the step (27 % of it): the grouped weight-gradient GEMM of one transformer block,
+    # dW_g[N,K] += dY_g^T . X_g for the 4 Linear layers, ONE launch.  Timed on its own with HIP events recorded on the
+    # stream it is launched on (torch's current stream); algorithmic FLOPs per launch = 2 M (4 D^2 + 2 D F).
     dom = None
     if rank == 0:
+        import ctypes
+        from touhouimageclassification_amd._lib import call, current_stream
         M, D, F = B * 197, m["hidden"], m["mlp"]
-        a = torch.randn(M, D, device=dev).to(torch.bfloat16)
-        w = (torch.randn(F, D, device=dev) * 0.02).to(torch.bfloat16)
-        bias = torch.zeros(F, device=dev)
+        shapes = [(D, F), (F, D), (D, D), (3 * D, D)]
+        As = [torch.randn(M, n, device=dev).to(torch.bfloat16) for n, k in shapes]
+        Bs = [torch.randn(M, k, device=dev).to(torch.bfloat16) for n, k in shapes]
+        Cs = [torch.zeros(n, k, device=dev) for n, k in shapes]
+        PA = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in As])
+        PB = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in Bs])
+        PC = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in Cs])
+        NN = (ctypes.c_int * 4)(*[s_[0] for s_ in shapes])
+        KK = (ctypes.c_int * 4)(*[s_[1] for s_ in shapes])
+
+        def launch():
+            call("tic_gemm_tn_group_bf16", 4, PA, PB, PC, NN, KK, M, current_stream())
         for _ in range(3):
-            ops.gemm_nt(a, w, ops.EPI_GELU, bias=bias)
+            launch()
         reps = 20
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        outs = [torch.empty(M, F, dtype=torch.bfloat16, device=dev) for _ in range(2)]
-        from touhouimageclassification_amd._lib import call, current_stream
         e0.record()
         for _ in range(reps):
-            call("tic_gemm_nt_bf16", a.data_ptr(), w.data_ptr(), M, F, D, 1, bias.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(),
-                 None, None, None, None, 0, current_stream())
+            launch()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        dom = dict(kernel="gemm_nt256_kernel<GELU> (fc1 + bias + GELU, stores u and gelu(u))", shape=[M, F, D], ms=round(ms, 4),
-                   tflops=round(2.0 * M * F * D / (ms * 1e-3) / 1e12, 1))
+        kflops = 2.0 * M * sum(n * k for n, k in shapes)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        if os.path.exists(tf):
+            rec = json.load(open(tf))
+            if rec.get("M") == M and rec.get("hidden") == D:
+                traffic = rec["hbm_bytes_per_launch"]
+        dom = dict(kernel="gemm_tn256_streamk_kernel (grouped dW of one block)", M=M, flops_per_launch=kflops, ms=round(ms, 4),
+                   tflops=round(kflops / (ms * 1e-3) / 1e12, 1), traffic=traffic)
+        del As, Bs, Cs
 
     if rank == 0:
         ips = world * B * args.steps / dt
@@ -200,9 +217,12 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "tokens": 197, "parallelism": f"dp{world}",
                        "optimizer": "AdamW lr=1e-5 wd=0.01 (fused, fp32 master weights)", "step_driver": "autograd" if args.autograd else "fused", "gpu_augmentation": bool(args.aug)},
             "loss": round(loss_v, 5),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "flops_per_image": fl, "dominant_kernel": dom},
+            # dominant kernel (contract): algorithmic FLOPs per launch / its average launch duration (HIP events, live)
+            "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": dom["traffic"],
+                         "kernel": dom["kernel"], "M": dom["M"], "flops_per_launch": dom["flops_per_launch"], "ms_per_launch": dom["ms"],
+                         # whole step: img/s x 369.32 GFLOP/img / n_gpus vs the same peak
+                         "step_achieved": round(achieved, 1), "step_frac": round(achieved / PEAK_BF16_TFLOPS, 4), "flops_per_image": fl},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, C)
