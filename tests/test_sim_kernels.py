@@ -96,3 +96,14 @@ def test_mix(env):
 
 def test_fused_bias_gradients(env):
     kc.check_fused_bias_gradients(env)
+
+
+def test_gemm_tn_group_phase_aligned_split(env):
+    """16 shares over 8 tiles: per 'XCD' one main workgroup (steps [0, S/2)) and one tail workgroup (steps [S/2, S))"""
+    call("tic_set_option", b"gemm_tile", 256)
+    call("tic_set_option", b"tn_streamk", 16)
+    try:
+        kc.check_gemm_tn_group(env, 333, [(512, 512), (256, 1024)])
+    finally:
+        call("tic_set_option", b"gemm_tile", 0)
+        call("tic_set_option", b"tn_streamk", 1)

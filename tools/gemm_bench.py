@@ -92,13 +92,15 @@ def tn_group(M, D, F, dev):
     NN = (ctypes.c_int * n)(*[s_[0] for s_ in shapes])
     KK = (ctypes.c_int * n)(*[s_[1] for s_ in shapes])
     fl = sum(2.0 * M * a * b for a, b in shapes)
-    for tile, sk in ((128, 0), (256, 0), (256, 1), (256, 0), (256, 1)):
-        call("tic_set_option", b"gemm_tile", tile)
+    for name, sk, ph in (("one tile per CU", 0, 0), ("stream-K flat", 1, 0), ("stream-K phase-aligned", 1, 1)) * 2:
+        call("tic_set_option", b"gemm_tile", 256)
         call("tic_set_option", b"tn_streamk", sk)
+        call("tic_set_option", b"tn_phase", ph)
         ms = time_ms(lambda: call("tic_gemm_tn_group_bf16", n, PA, PB, PC, NN, KK, M, current_stream()))
-        print(f"M={M} dW group of 4 (tile {tile}, stream-K {sk}): {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF", flush=True)
+        print(f"M={M} dW group of 4 ({name}): {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF", flush=True)
     call("tic_set_option", b"gemm_tile", 0)
     call("tic_set_option", b"tn_streamk", 1)
+    call("tic_set_option", b"tn_phase", 1)
 
 
 if __name__ == "__main__":

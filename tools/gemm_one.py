@@ -19,10 +19,12 @@ ap.add_argument("--epi", type=int, default=0)
 ap.add_argument("--tile", type=int, default=256)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--streamk", type=int, default=1)
+ap.add_argument("--phase", type=int, default=1)
 a = ap.parse_args()
 dev = torch.device("cuda")
 call("tic_set_option", b"gemm_tile", a.tile)
 call("tic_set_option", b"tn_streamk", a.streamk)
+call("tic_set_option", b"tn_phase", a.phase)
 M, N, K = a.M, a.N, a.K
 if a.kind == "nt":
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)

@@ -204,12 +204,33 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
     tn256_tile_segment<false>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, (gp.M + 63) / 64);
 }
 
-// Stream-K form: the flattened (tile, M step) space is cut into gridDim.x equal contiguous shares (0.75 tile per CU
-// for a ViT-L block on 256 CUs instead of 192 busy + 64 idle CUs); a share is processed as the 1-2 segments it has
-// inside single tiles, each through the pipelined tile routine (the pipeline restarts once at a tile boundary), and
-// every partial tile is ADDED to C with fp32 atomics.  Flushes of different workgroups fall at different times and
-// overlap the others' MFMA work.
-__global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_kernel(GemmTnGroupParams gp, int nsteps) {
+// Stream-K forms: every CU gets an equal share of the (tile, M step) work instead of 192 busy + 64 idle CUs.  A share is
+// processed as the segments it has inside single tiles, each through the pipelined tile routine, and every partial
+// tile is ADDED to C with fp32 atomics.
+//
+// s_main > 0 -- PHASE-ALIGNED split (used when the tile count allows it, e.g. ViT-L: 192 tiles = 8 XCDs x 24):
+//   per XCD, `tpx` "main" workgroups take steps [0, s_main) of one tile each and the remaining 32 - tpx "tail"
+//   workgroups take steps [s_main, S) of `tail_each` tiles of the SAME XCD.  All main CUs sweep the same rows at the same
+//   time and so do the tail CUs (lock-step row slabs are what the L2 / Infinity Cache can share: the flat split below
+//   fetched 2x the bytes of the lock-step kernel because its shares start at 256 different row offsets).
+// s_main == 0 -- FLAT split: the flattened (tile, step) space cut into gridDim.x equal contiguous shares.
+__global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
+    const bf16_t *Ap, *Bp;
+    float* Cp;
+    int N, K, n0, k0;
+    if (s_main > 0) {
+        const int xcd = TIC_BID_X & 7, idx = TIC_BID_X >> 3;   // blocks b, b+8, ... share an XCD (speed only, never correctness)
+        if (idx < tpx) {
+            tn_tile_lookup(gp, xcd * tpx + idx, Ap, Bp, Cp, N, K, n0, k0);
+            tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, s_main);
+        } else {
+            for (int j = 0; j < tail_each; ++j) {
+                tn_tile_lookup(gp, xcd * tpx + (idx - tpx) * tail_each + j, Ap, Bp, Cp, N, K, n0, k0);
+                tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s_main, nsteps);
+            }
+        }
+        return;
+    }
     const long total_units = (long)gp.total_tiles * nsteps;
     int u = (int)(total_units * TIC_BID_X / TIC_NBLK_X);
     const int u1 = (int)(total_units * (TIC_BID_X + 1) / TIC_NBLK_X);
@@ -217,9 +238,6 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_kernel(GemmTnGroupP
         const int tile = u / nsteps, s0 = u - tile * nsteps;
         int s1 = s0 + (u1 - u);
         if (s1 > nsteps) s1 = nsteps;
-        const bf16_t *Ap, *Bp;
-        float* Cp;
-        int N, K, n0, k0;
         tn_tile_lookup(gp, tile, Ap, Bp, Cp, N, K, n0, k0);
         tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s0, s1);
         u += s1 - s0;

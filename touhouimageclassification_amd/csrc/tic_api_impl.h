@@ -46,9 +46,14 @@ static int tic_after_launch(const char* what) {
 // "tn_streamk" = 1 (default: grouped dW as 256 equal stream-K shares) | 0 (one workgroup per full-M tile)
 static int g_opt_gemm_tile = 0;
 static int g_opt_tn_streamk = 1;
+static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 extern "C" int tic_set_option(const char* name, int value) {
     if (name && !strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) {
         g_opt_gemm_tile = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "tn_phase") && (value == 0 || value == 1)) {
+        g_opt_tn_phase = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "tn_streamk") && value >= 0 && value <= 4096) {   // 0 off, 1 = 256 shares, n > 1 = n shares (tests)
@@ -174,8 +179,19 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
         const int nsteps = (M + 63) / 64;
         const long shares = g_opt_tn_streamk == 1 ? 256 : g_opt_tn_streamk;   // one share per CU by default
         if (g_opt_tn_streamk && (long)t * nsteps >= shares) {
+            // phase-aligned split when the tiles divide over the 8 XCDs and the tail workgroups get whole tiles
+            int s_main = 0, tpx = 0, tail_each = 0;
+            if (g_opt_tn_phase && shares % 8 == 0 && t % 8 == 0) {
+                const int per_xcd = (int)(shares / 8), tp = t / 8, tails = per_xcd - tp;
+                if (tails > 0 && tp % tails == 0) {
+                    tpx = tp;
+                    tail_each = tp / tails;
+                    s_main = (int)((long)nsteps * tail_each / (tail_each + 1));   // main: s_main steps; tail: tail_each x (S - s_main)
+                    if (s_main < 1 || s_main >= nsteps) s_main = 0;
+                }
+            }
             TIC_RT_MAX_LDS(gemm_tn256_streamk_kernel, G256_LDS_BYTES);
-            TIC_LAUNCH(gemm_tn256_streamk_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps);
+            TIC_LAUNCH(gemm_tn256_streamk_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
             return tic_after_launch("gemm_tn_group(stream-K)");
         }
         TIC_RT_MAX_LDS(gemm_tn256_kernel, G256_LDS_BYTES);
