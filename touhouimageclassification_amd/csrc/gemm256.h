@@ -34,9 +34,6 @@
 #define G256_BUF_BYTES 65536u   // A 32 KiB + B 32 KiB
 #define G256_LDS_BYTES (2u * G256_BUF_BYTES)
 
-struct TrueTag { static constexpr bool value = true; };
-struct FalseTag { static constexpr bool value = false; };
-
 TIC_DEV void g256_barrier() {
 #ifndef TIC_SIM
     asm volatile("" ::: "memory");
