@@ -193,4 +193,4 @@ def test_serve_full_judge(tmp_path):
     pred, conf = sv.full_judge(m2, tf, c2i, image=str(data / "alice" / "0.png"), device="cpu", output="x", staging=64)
     assert pred in c2i and 0.0 < conf <= 1.0
     with pytest.raises(ValueError):
-        sv.get_model("resmoe", 2)
+        sv.get_model("no-such-model", 2)

@@ -9,7 +9,7 @@ correct,path) and top-1 accuracy -- the protocol behind the published accuracies
 
 The reference pushes ONE image at a time through PIL resize + the model; here a folder is evaluated in batches: raw
 uint8 thumbnails -> one HIP resize/normalise kernel -> the HIP forward.  ``full_judge`` also reports top-5.
-ResMoE ('resmoe', serve.py:42) is not built yet.
+'resmoe' (serve.py:42) returns the dense MoE of ``ResMoE/train.get_model`` (its forward returns a tuple whose first element is the logits).
 """
 from __future__ import annotations
 
@@ -43,6 +43,9 @@ def get_model(model_type: str, num_classes: int):
         return ViT(num_classes=num_classes, pretrained=False, model_name='google/vit-base-patch16-224-in21k', wrap_model_name=False)
     if kind == 'vit-large':
         return ViT(num_classes=num_classes, pretrained=False, model_name='google/vit-large-patch16-224-in21k', wrap_model_name=False)
+    if kind == 'resmoe':
+        from ..ResMoE import train as moet
+        return moet.get_model()
     raise ValueError(f"Unsupported model type: {model_type}")
 
 
@@ -60,6 +63,8 @@ def load_model(model_type: str, num_classes: int, weights_path: Optional[str] = 
 
 def _logits(model, x):
     out = model(x)
+    if isinstance(out, tuple):      # MoEClassifier: (combined logits, gate weights, top-k indices)
+        return out[0]
     return out.logits if hasattr(out, 'logits') else out
 
 
