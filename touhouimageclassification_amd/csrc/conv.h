@@ -134,13 +134,15 @@ __global__ void __launch_bounds__(256) col2im_kernel(const bf16_t* __restrict__ 
 }
 
 // ---- BatchNorm (train mode) over [M, C] bf16, C % 8 == 0 ------------------------------------------------
-// sums[0..C) += sum_m x, sums[C..2C) += sum_m x^2 ; grid (ceil(C/256), row_splits), LDS 2*8*256 floats
+// sums[0..C) += sum_m x, sums[C..2C) += sum_m x^2.  A block covers cpb = min(C/8, 32) 8-channel chunks with R = 256/cpb
+// row lanes (so narrow layers -- C = 64 -- still use every thread); grid (ceil(C/256), row_splits); LDS 2*2048 floats.
 __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums, long M, int C) {
-    const int tx = TIC_TID & 31, ty = TIC_TID >> 5;
+    const int cpb = (C / 8) < 32 ? (C / 8) : 32, R = 256 / cpb;
+    const int tx = TIC_TID % cpb, ty = TIC_TID / cpb;
     const int c0 = TIC_BID_X * 256 + tx * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c0 < C) {
-        for (long m = (long)TIC_BID_Y * 8 + ty; m < M; m += (long)TIC_NBLK_Y * 8) {
+        for (long m = (long)TIC_BID_Y * R + ty; m < M; m += (long)TIC_NBLK_Y * R) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + m * C + c0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -152,20 +154,19 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict_
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        lds_stf((uint32_t)(ty * 256 + tx * 8 + j) * 4u, s[j]);
-        lds_stf((uint32_t)(2048 + ty * 256 + tx * 8 + j) * 4u, q[j]);
+        lds_stf((uint32_t)(TIC_TID * 8 + j) * 4u, s[j]);            // [ty][tx][j]
+        lds_stf((uint32_t)(2048 + TIC_TID * 8 + j) * 4u, q[j]);
     }
     block_sync();
-    const int c = TIC_BID_X * 256 + TIC_TID;
-    if (c < C) {
+    const int cw = cpb * 8;                                           // channels covered by this block
+    if (TIC_TID < cw && TIC_BID_X * 256 + TIC_TID < C) {
         float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            a += lds_ldf((uint32_t)(k * 256 + TIC_TID) * 4u);
-            b += lds_ldf((uint32_t)(2048 + k * 256 + TIC_TID) * 4u);
+        for (int k = 0; k < R; ++k) {
+            a += lds_ldf((uint32_t)(k * cw + TIC_TID) * 4u);
+            b += lds_ldf((uint32_t)(2048 + k * cw + TIC_TID) * 4u);
         }
-        atomic_addf(sums + c, a);
-        atomic_addf(sums + C + c, b);
+        atomic_addf(sums + TIC_BID_X * 256 + TIC_TID, a);
+        atomic_addf(sums + C + TIC_BID_X * 256 + TIC_TID, b);
     }
 }
 // train: mean/rstd from the batch sums, running stats updated (unbiased var), counter += 1; eval: from running stats
@@ -195,8 +196,16 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
                                                         bf16_t* __restrict__ y, long M, int C, int relu) {
     const int cpr = C / 8;
     const long total = M * cpr;
-    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
-        const int c0 = (int)(i % cpr) * 8;
+    const long first = (long)TIC_BID_X * 256 + TIC_TID, step = (long)TIC_NBLK_X * 256;
+    // the launcher makes `step` a multiple of cpr, so a thread keeps ONE 8-channel chunk: per-channel scale / shift in registers
+    const int c0 = (int)(first % cpr) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = rstd[c0 + j] * gamma[c0 + j];
+        sh[j] = beta[c0 + j] - mean[c0 + j] * sc[j];
+    }
+    for (long i = first; i < total; i += step) {
         const long off = (i / cpr) * C + c0;
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + off);
         bf16x8 idv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -204,17 +213,18 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float f = (bf2f((bf16_t)v[j]) - mean[c0 + j]) * rstd[c0 + j] * gamma[c0 + j] + beta[c0 + j];
+            float f = bf2f((bf16_t)v[j]) * sc[j] + sh[j];
             if (identity) f += bf2f((bf16_t)idv[j]);
             o[j] = (relu && f < 0.f) ? 0.f : f;
         }
         *reinterpret_cast<u32x4*>(y + off) = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
     }
 }
-// dz = dy * [y > 0] (if y given);  red[0..C) += sum dz ; red[C..2C) += sum dz * xhat
+// dz = dy * [y > 0] (if y given);  red[0..C) += sum dz ; red[C..2C) += sum dz * xhat   (same thread mapping as bn_stats)
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, const bf16_t* y, const bf16_t* __restrict__ x,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ red, long M, int C) {
-    const int tx = TIC_TID & 31, ty = TIC_TID >> 5;
+    const int cpb = (C / 8) < 32 ? (C / 8) : 32, R = 256 / cpb;
+    const int tx = TIC_TID % cpb, ty = TIC_TID / cpb;
     const int c0 = TIC_BID_X * 256 + tx * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c0 < C) {
@@ -224,7 +234,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
             mu[j] = mean[c0 + j];
             rs[j] = rstd[c0 + j];
         }
-        for (long m = (long)TIC_BID_Y * 8 + ty; m < M; m += (long)TIC_NBLK_Y * 8) {
+        for (long m = (long)TIC_BID_Y * R + ty; m < M; m += (long)TIC_NBLK_Y * R) {
             const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + m * C + c0);
             const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + m * C + c0);
             bf16x8 yv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -240,20 +250,19 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        lds_stf((uint32_t)(ty * 256 + tx * 8 + j) * 4u, s[j]);
-        lds_stf((uint32_t)(2048 + ty * 256 + tx * 8 + j) * 4u, q[j]);
+        lds_stf((uint32_t)(TIC_TID * 8 + j) * 4u, s[j]);
+        lds_stf((uint32_t)(2048 + TIC_TID * 8 + j) * 4u, q[j]);
     }
     block_sync();
-    const int c = TIC_BID_X * 256 + TIC_TID;
-    if (c < C) {
+    const int cw = cpb * 8;
+    if (TIC_TID < cw && TIC_BID_X * 256 + TIC_TID < C) {
         float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            a += lds_ldf((uint32_t)(k * 256 + TIC_TID) * 4u);
-            b += lds_ldf((uint32_t)(2048 + k * 256 + TIC_TID) * 4u);
+        for (int k = 0; k < R; ++k) {
+            a += lds_ldf((uint32_t)(k * cw + TIC_TID) * 4u);
+            b += lds_ldf((uint32_t)(2048 + k * cw + TIC_TID) * 4u);
         }
-        atomic_addf(red + c, a);
-        atomic_addf(red + C + c, b);
+        atomic_addf(red + TIC_BID_X * 256 + TIC_TID, a);
+        atomic_addf(red + C + TIC_BID_X * 256 + TIC_TID, b);
     }
 }
 // dx = gamma rstd (dz - dbeta/M - xhat dgamma/M);  dskip (optional) (+)= dz  (the identity-path gradient)
@@ -263,8 +272,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     const int cpr = C / 8;
     const long total = M * cpr;
     const float invM = 1.0f / (float)M;
-    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
-        const int c0 = (int)(i % cpr) * 8;
+    const long first = (long)TIC_BID_X * 256 + TIC_TID, step = (long)TIC_NBLK_X * 256;
+    const int c0 = (int)(first % cpr) * 8;   // invariant per thread (step % cpr == 0): per-channel terms live in registers
+    float mu[8], rs[8], k0[8], k1[8], k2[8];  // dx = k0 dz - k1 - xhat k2
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = mean[c0 + j];
+        rs[j] = rstd[c0 + j];
+        k0[j] = gamma[c0 + j] * rs[j];
+        k1[j] = k0[j] * red[c0 + j] * invM;
+        k2[j] = k0[j] * red[C + c0 + j] * invM;
+    }
+    for (long i = first; i < total; i += step) {
         const long off = (i / cpr) * C + c0;
         const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + off);
         const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + off);
@@ -275,8 +294,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
         for (int j = 0; j < 8; ++j) {
             float dz = bf2f((bf16_t)d[j]);
             if (y && !(bf2f((bf16_t)yv[j]) > 0.f)) dz = 0.f;
-            const float xh = (bf2f((bf16_t)xv[j]) - mean[c0 + j]) * rstd[c0 + j];
-            o[j] = gamma[c0 + j] * rstd[c0 + j] * (dz - red[c0 + j] * invM - xh * red[C + c0 + j] * invM);
+            const float xh = (bf2f((bf16_t)xv[j]) - mu[j]) * rs[j];
+            o[j] = k0[j] * dz - k1[j] - xh * k2[j];
             z[j] = dz;
         }
         *reinterpret_cast<u32x4*>(dx + off) = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};

@@ -426,15 +426,15 @@ extern "C" int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, 
     TIC_LAUNCH(col2im_kernel, ew_grid((long)B * H * W * (Ci / 8)), 256, 0, stream, (const bf16_t*)dcol, (bf16_t*)dx, g, accumulate);
     return tic_after_launch("col2im");
 }
-static int bn_rows(long M) {
-    long r = (M + 63) / 64;
-    return (int)(r > 128 ? 128 : (r < 1 ? 1 : r));
+static int bn_rows(long M) {   // row splits of the column-reduction kernels: up to 4 blocks per CU at the big layers
+    long r = (M + 255) / 256;
+    return (int)(r > 1024 ? 1024 : (r < 1 ? 1 : r));
 }
 extern "C" int tic_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                  int64_t* num_batches, float* mean, float* rstd, float* scratch2c, const void* identity, void* y, long M, int C,
                                  float eps, float momentum, int train, int relu, tic_stream_t stream) {
     TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && scratch2c && y, "batchnorm_fwd: null pointer");
-    TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0, "batchnorm_fwd: need C %% 8 == 0");
+    TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_fwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
     if (train) {
         TIC_RT_MEMSET(scratch2c, 0, (size_t)2 * C * 4, stream);
         TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, scratch2c, M, C);
@@ -455,7 +455,7 @@ extern "C" int tic_batchnorm_bwd(const void* dy, const void* y_or_null, const vo
                                  float* scratch2c, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M, int C,
                                  tic_stream_t stream) {
     TIC_REQUIRE(dy && x && mean && rstd && gamma && scratch2c && dx && dgamma && dbeta, "batchnorm_bwd: null pointer");
-    TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0, "batchnorm_bwd: need C %% 8 == 0");
+    TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_bwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
     TIC_RT_MEMSET(scratch2c, 0, (size_t)2 * C * 4, stream);
     TIC_LAUNCH(bn_bwd_reduce_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null,
                (const bf16_t*)x, mean, rstd, scratch2c, M, C);
