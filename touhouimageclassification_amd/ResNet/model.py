@@ -124,10 +124,19 @@ class TicResNet(nn.Module):
         return out
 
     def _pack(self, conv: _Conv, transposed: bool):
-        kp = conv.kp
-        out = torch.empty((kp, conv.cout) if transposed else (conv.cout, kp), dtype=torch.bfloat16, device=conv.weight.device)
-        self._call("tic_conv_weight_pack", conv.weight.data_ptr(), out.data_ptr(), conv.cout, conv.cin, conv.k, conv.k, 1 if transposed else 0)
-        return out
+        """bf16 GEMM operand of a conv weight ([Cout, Kp] or its transpose), re-packed only when the fp32 weight changed"""
+        w = conv.weight
+        key = (w._version, w.data_ptr(), w.device)
+        cache = conv.__dict__.setdefault("_packed", {})
+        if cache.get("key") != key:
+            cache.clear()
+            cache["key"] = key
+        if transposed not in cache:
+            kp = conv.kp
+            out = torch.empty((kp, conv.cout) if transposed else (conv.cout, kp), dtype=torch.bfloat16, device=w.device)
+            self._call("tic_conv_weight_pack", w.data_ptr(), out.data_ptr(), conv.cout, conv.cin, conv.k, conv.k, 1 if transposed else 0)
+            cache[transposed] = out
+        return cache[transposed]
 
     def _conv_fwd(self, conv: _Conv, x, B, H, W):
         """x [B,H,W,Cin] bf16 -> (y [M,Cout] bf16, col or None, Ho, Wo)"""
@@ -157,10 +166,35 @@ class TicResNet(nn.Module):
             p.grad = torch.zeros_like(p)
         return p.grad
 
+    def _begin_backward(self, dev):
+        """One flat fp32 buffer backs every .grad (zeroed by ONE fill when the optimizer dropped the grads) and one
+        flat scratch holds the [Cout, Kp] weight-gradient GEMM outputs of all convs."""
+        params = [p for p in self.parameters() if p.requires_grad]
+        flat = self.__dict__.get("_flat_grad")
+        total = sum(p.numel() for p in params)
+        if flat is None or flat.device != dev or flat.numel() != total:
+            flat = self.__dict__["_flat_grad"] = torch.empty(total, dtype=torch.float32, device=dev)
+        if all(p.grad is None for p in params):
+            flat.zero_()
+            off = 0
+            for p in params:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        convs = [m for m in self.modules() if isinstance(m, _Conv)]
+        need = sum(c.cout * c.kp for c in convs)
+        dws = self.__dict__.get("_dw_scratch")
+        if dws is None or dws.device != dev or dws.numel() != need:
+            dws = self.__dict__["_dw_scratch"] = torch.empty(need, dtype=torch.float32, device=dev)
+            off = 0
+            for c in convs:
+                c.__dict__["_dw_view"] = dws[off:off + c.cout * c.kp]
+                off += c.cout * c.kp
+        dws.zero_()
+
     def _conv_bwd(self, conv: _Conv, dy, col, B, H, W, need_dx: bool, dx_accumulate_into=None):
         """dy [M,Cout]; returns dx [B*H*W, Cin] bf16 (or None) and accumulates the weight gradient"""
         M = dy.shape[0]
-        dw = torch.zeros(conv.cout, conv.kp, dtype=torch.float32, device=dy.device)
+        dw = conv.__dict__["_dw_view"]   # zeroed by _begin_backward
         self._call("tic_gemm_tn_bf16", dy.data_ptr(), col.data_ptr(), dw.data_ptr(), M, conv.cout, conv.kp)
         self._call("tic_conv_weight_grad", dw.data_ptr(), self._grad_buf(conv.weight).data_ptr(), conv.cout, conv.cin, conv.k, conv.k)
         if not need_dx:
@@ -236,6 +270,7 @@ class TicResNet(nn.Module):
         B = tape["B"]
         z, Hc, Wc, feat = tape["head"]
         dev = dlogits.device
+        self._begin_backward(dev)
         dz = torch.empty(B, feat, dtype=torch.bfloat16, device=dev)
         self._call("tic_head_bwd", dlogits.data_ptr(), z.data_ptr(), self.fc.weight.data_ptr(), dz.data_ptr(), self._grad_buf(self.fc.weight).data_ptr(),
                    self._grad_buf(self.fc.bias).data_ptr(), B, self.num_classes, feat)

@@ -338,40 +338,57 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const bf16_t* __restri
             u32x4{pack2bf(mx[0], mx[1]), pack2bf(mx[2], mx[3]), pack2bf(mx[4], mx[5]), pack2bf(mx[6], mx[7])};
     }
 }
-// gather form: an input pixel receives dy of every window whose FIRST maximum (scan order) it is
+// gather form: an input pixel receives dy of every window whose FIRST maximum (scan order) it is.
+// One thread per (pixel, 8 channels); per window only the positions scanned before this pixel are re-read.
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
                                                            bf16_t* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
-    const long total = (long)B * H * W * C;
+    const int cpr = C / 8;
+    const long total = (long)B * H * W * cpr;
     for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c0 = (int)(i % cpr) * 8;
+        long t = i / cpr;
         const int ix = (int)(t % W);
         t /= W;
         const int iy = (int)(t % H), b = (int)(t / H);
-        const bf16_t xv = x[i];
-        float acc = 0.f;
-        for (int oy = (iy - 1 + 1) / 2; oy <= (iy + 1) / 2 && oy < Ho; ++oy) {
-            if (oy < 0) continue;
-            for (int ox = (ix - 1 + 1) / 2; ox <= (ix + 1) / 2 && ox < Wo; ++ox) {
-                if (ox < 0) continue;
-                const long oo = (((long)b * Ho + oy) * Wo + ox) * C + c;
-                if (y[oo] != xv) continue;
-                // is (iy, ix) the first position of this window holding the maximum?
-                bool first = true;
-                for (int ky = 0; ky < 3 && first; ++ky) {
+        const bf16x8 xr = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        float xv[8], acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xv[j] = bf2f((bf16_t)xr[j]);
+            acc[j] = 0.f;
+        }
+        const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;   // windows holding row iy: 2 oy - 1 <= iy <= 2 oy + 1
+        for (int oy = oy0; oy <= oy1 && oy < Ho; ++oy) {
+            for (int ox = ox0; ox <= ox1 && ox < Wo; ++ox) {
+                const long oo = (((long)b * Ho + oy) * Wo + ox) * C + c0;
+                const bf16x8 yr = *reinterpret_cast<const bf16x8*>(y + oo);
+                bool m[8], any = false;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    m[j] = bf2f((bf16_t)yr[j]) == xv[j];
+                    any |= m[j];
+                }
+                if (!any) continue;
+                const int py = iy - (oy * 2 - 1), px = ix - (ox * 2 - 1);   // my position inside the window
+                for (int ky = 0; ky <= py; ++ky) {
                     const int yy = oy * 2 + ky - 1;
-                    if (yy < 0 || yy >= H) continue;
-                    for (int kx = 0; kx < 3; ++kx) {
+                    if (yy < 0) continue;
+                    const int kend = ky < py ? 3 : px;
+                    for (int kx = 0; kx < kend; ++kx) {
                         const int xx = ox * 2 + kx - 1;
                         if (xx < 0 || xx >= W) continue;
-                        if (yy == iy && xx == ix) { ky = 3; break; }
-                        if (x[(((long)b * H + yy) * W + xx) * C + c] == xv) { first = false; break; }
+                        const bf16x8 e = *reinterpret_cast<const bf16x8*>(x + (((long)b * H + yy) * W + xx) * C + c0);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) m[j] = m[j] && !(bf2f((bf16_t)e[j]) == xv[j]);
                     }
                 }
-                if (first) acc += bf2f(dy[oo]);
+                const bf16x8 dr = *reinterpret_cast<const bf16x8*>(dy + oo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += m[j] ? bf2f((bf16_t)dr[j]) : 0.f;
             }
         }
-        dx[i] = f2bf(acc);
+        *reinterpret_cast<u32x4*>(dx + i * 8) =
+            u32x4{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
     }
 }
 // [B, HW, C] -> [B, C] mean ; backward broadcast / HW

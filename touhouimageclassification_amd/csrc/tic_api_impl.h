@@ -471,9 +471,9 @@ extern "C" int tic_maxpool3x3s2_fwd(const void* x, void* y, int B, int H, int W,
     return tic_after_launch("maxpool_fwd");
 }
 extern "C" int tic_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, tic_stream_t stream) {
-    TIC_REQUIRE(x && y && dy && dx, "maxpool_bwd: null pointer");
+    TIC_REQUIRE(x && y && dy && dx && C % 8 == 0, "maxpool_bwd: null pointer or C %% 8 != 0");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    TIC_LAUNCH(maxpool_bwd_kernel, ew_grid((long)B * H * W * C), 256, 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, Ho, Wo);
+    TIC_LAUNCH(maxpool_bwd_kernel, ew_grid((long)B * H * W * (C / 8)), 256, 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, Ho, Wo);
     return tic_after_launch("maxpool_bwd");
 }
 extern "C" int tic_avgpool_fwd(const void* x, void* y, int B, int HW, int C, tic_stream_t stream) {
