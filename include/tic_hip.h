@@ -40,6 +40,9 @@ int tic_set_option(const char* name, int value);
 #define TIC_EPI_RESID 2 /* out_f32 = resid + bf16(acc + bias)                       o_proj / fc2 + residual */
 #define TIC_EPI_DGELU 3 /* out = bf16(bf16(acc) * gelu'(aux))                       backward through GELU */
 #define TIC_EPI_PATCH 4 /* out_f32[(m/P)*(P+1)+1+m%P] = bf16(acc+bias) + rowtab[1+m%P]   patch embed + pos */
+#define TIC_EPI_GELU_DG 5 /* u = bf16(acc + bias); out = bf16(gelu'(u)); out2 = bf16(gelu_erf(u))   fc1 + GELU, derivative saved
+                             instead of the pre-activation: the erf / exp work is shared and the backward becomes one multiply */
+#define TIC_EPI_MULAUX 6  /* out = bf16(bf16(acc) * aux)                               backward through GELU with aux = gelu'(u) */
 
 /* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  N % 8 == 0, K % 64 == 0, any M >= 1.
  * Replaces nn.Linear forward (HF:202-205,216-218,235-236,246-247,250-252) and, fed with W^T, the dX half
@@ -48,7 +51,7 @@ int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int epil
                      void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
                      const void* aux_bf16, const float* rowtab, int patches, tic_stream_t stream);
 
-/* same, plus colsum (optional, fp32 [N]) += column sums of the stored output (EPI_BF16 / EPI_DGELU): the bias gradient
+/* same, plus colsum (optional, fp32 [N]) += column sums of the stored output (EPI_BF16 / EPI_DGELU / EPI_MULAUX): the bias gradient
  * of the Linear whose output gradient this GEMM produces, fused into the epilogue */
 int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
                         void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
@@ -180,7 +183,7 @@ typedef struct {
     long t_layer_stride, t_wqkv, t_wo, t_w1, t_w2, t_total;
     /* byte offsets into the activation workspace */
     size_t P, hs, hs_stride, layer_ws, layer_ws_stride;
-    size_t a1, mean1, rstd1, qkv, lse, o, hmid, a2, mean2, rstd2, u, g; /* inside a layer_ws block */
+    size_t a1, mean1, rstd1, qkv, lse, o, hmid, a2, mean2, rstd2, u, g; /* inside a layer_ws block; u holds gelu'(fc1 out) */
     size_t zf, meanf, rstdf, logits, dlogits, dzf, dh, dhb, dhb2, du, da, dqkv, dpatch;
     size_t ws_bytes;
 } TicVitLayout;

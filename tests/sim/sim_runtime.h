@@ -329,6 +329,7 @@ TIC_DEV int wave_id() { return sim::st().cur->tid >> 6; }
 TIC_DEV uint32_t uniform(uint32_t v) { return v; }
 TIC_DEV void atomic_addf(float* p, float v) { *p += v; }
 TIC_DEV float fast_exp2(float x) { return exp2f(x); }
+TIC_DEV float fast_rcp(float x) { return 1.0f / x; }
 TIC_DEV float fast_log2(float x) { return log2f(x); }
 
 #define TIC_TID (sim::st().cur->tid)

@@ -58,7 +58,7 @@ TIC_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& tm, in
 // row) is fetched one row AHEAD of its use, so the loads of row r+1 fly while row r is computed and stored.
 struct EpiExtra {
     f32x4 f;   // RESID: residual, PATCH: position-embedding row
-    u32x2 u;   // DGELU: 4 bf16 pre-activations
+    u32x2 u;   // DGELU: 4 bf16 pre-activations, MULAUX: 4 bf16 multipliers
 };
 template <int EPI>
 TIC_DEV EpiExtra epi_fetch(const GemmNtParams& p, int m, int n) {
@@ -67,7 +67,7 @@ TIC_DEV EpiExtra epi_fetch(const GemmNtParams& p, int m, int n) {
     e.u = u32x2{0u, 0u};
     if (m < p.M && n < p.N) {
         if (EPI == TIC_EPI_RESID) e.f = *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.N + n);
-        if (EPI == TIC_EPI_DGELU) e.u = *reinterpret_cast<const u32x2*>(p.aux + (size_t)m * p.N + n);
+        if (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX) e.u = *reinterpret_cast<const u32x2*>(p.aux + (size_t)m * p.N + n);
         if (EPI == TIC_EPI_PATCH) e.f = *reinterpret_cast<const f32x4*>(p.rowtab + (size_t)(1 + m % p.patches) * p.N + n);
     }
     return e;
@@ -76,7 +76,7 @@ TIC_DEV EpiExtra epi_fetch(const GemmNtParams& p, int m, int n) {
 template <int EPI>
 TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias, EpiExtra e) {
     if (m >= p.M || n >= p.N) return f32x4{0.f, 0.f, 0.f, 0.f};   // ragged M; N not a multiple of the tile (conv channels 64, C*k*k ...)
-    if (EPI != TIC_EPI_DGELU) v += bias;
+    if (EPI != TIC_EPI_DGELU && EPI != TIC_EPI_MULAUX) v += bias;
     const size_t o = (size_t)m * p.N + n;
     if (EPI == TIC_EPI_BF16) {
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
@@ -102,6 +102,15 @@ TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias
         const float d2 = bfround(v[2]) * gelu_erf_grad(u2), d3 = bfround(v[3]) * gelu_erf_grad(u3);
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
         return f32x4{d0, d1, d2, d3};
+    } else if (EPI == TIC_EPI_GELU_DG) {
+        const GeluPair lo = gelu_pair(f32x2{bfround(v[0]), bfround(v[1])}), hi = gelu_pair(f32x2{bfround(v[2]), bfround(v[3])});
+        *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(lo.dg[0], lo.dg[1]), pack2bf(hi.dg[0], hi.dg[1])};
+        *reinterpret_cast<u32x2*>(p.out2 + o) = u32x2{pack2bf(lo.g[0], lo.g[1]), pack2bf(hi.g[0], hi.g[1])};
+    } else if (EPI == TIC_EPI_MULAUX) {
+        const float d0 = bfround(v[0]) * bf2f((bf16_t)(e.u[0] & 0xffff)), d1 = bfround(v[1]) * bf2f((bf16_t)(e.u[0] >> 16));
+        const float d2 = bfround(v[2]) * bf2f((bf16_t)(e.u[1] & 0xffff)), d3 = bfround(v[3]) * bf2f((bf16_t)(e.u[1] >> 16));
+        *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
+        return f32x4{d0, d1, d2, d3};
     } else if (EPI == TIC_EPI_PATCH) {
         const int img = m / p.patches, pi = m - img * p.patches;
         const size_t orow = (size_t)img * (p.patches + 1) + 1 + pi;
@@ -118,8 +127,9 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
     f32x4 bias[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
-        bias[g] = (EPI != TIC_EPI_DGELU && p.bias && col_of(g) < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col_of(g)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_PATCH);
+        bias[g] = (EPI != TIC_EPI_DGELU && EPI != TIC_EPI_MULAUX && p.bias && col_of(g) < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col_of(g)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX || EPI == TIC_EPI_PATCH);
+    constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
     EpiExtra ex[2][NG];
     f32x4 cs[NG];
 #pragma unroll
@@ -137,12 +147,12 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const f32x4 w4 = epi_store<EPI>(p, row_of(r), col_of(g), acc_of(r, g), bias[g], ex[r & 1][g]);
-            if (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU) cs[g] += w4;
+            if (HAS_COLSUM) cs[g] += w4;
         }
     }
     // fused bias gradient: this lane's rows are summed above; the 16 lanes that share (l>>4) hold the other rows of the
     // same 4 columns -> butterfly over lane bits 0..3, then one lane per column group adds to the global vector
-    if ((EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU) && p.colsum) {   // kernel-argument condition: wave-uniform
+    if (HAS_COLSUM && p.colsum) {   // kernel-argument condition: wave-uniform
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll

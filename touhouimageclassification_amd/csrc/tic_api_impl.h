@@ -79,7 +79,8 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
                                    void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
                                    const void* aux_bf16, const float* rowtab, int patches, float* colsum, tic_stream_t stream) {
     TIC_REQUIRE(A && B, "gemm_nt: null operand");
-    TIC_REQUIRE(!colsum || epilogue == TIC_EPI_BF16 || epilogue == TIC_EPI_DGELU, "gemm_nt: colsum is available for EPI_BF16 / EPI_DGELU only");
+    TIC_REQUIRE(!colsum || epilogue == TIC_EPI_BF16 || epilogue == TIC_EPI_DGELU || epilogue == TIC_EPI_MULAUX,
+                "gemm_nt: colsum is available for EPI_BF16 / EPI_DGELU / EPI_MULAUX only");
     TIC_REQUIRE(M >= 1 && N >= 8 && K >= 64, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
     TIC_REQUIRE(N % 8 == 0 && K % 64 == 0, "gemm_nt: need N %% 8 == 0 and K %% 64 == 0 (N=%d K=%d)", N, K);
     TIC_REQUIRE(TIC_ALIGNED16(A) && TIC_ALIGNED16(B), "gemm_nt: operands must be 16-byte aligned");
@@ -120,6 +121,14 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         case TIC_EPI_DGELU:
             TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_DGELU needs out_bf16 and aux_bf16");
             TIC_GEMM_NT_LAUNCH(TIC_EPI_DGELU);
+            break;
+        case TIC_EPI_GELU_DG:
+            TIC_REQUIRE(out_bf16 && out2_bf16, "gemm_nt: EPI_GELU_DG needs out_bf16 and out2_bf16");
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_GELU_DG);
+            break;
+        case TIC_EPI_MULAUX:
+            TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_MULAUX needs out_bf16 and aux_bf16");
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_MULAUX);
             break;
         case TIC_EPI_PATCH:
             TIC_REQUIRE(out_f32 && rowtab && patches > 0 && M % patches == 0, "gemm_nt: EPI_PATCH needs out_f32, rowtab, M %% patches == 0");
@@ -636,7 +645,7 @@ extern "C" int tic_vit_forward(const TicVitState* st, const float* x, float* log
         TIC_TRY(tic_attention_fwd(a + y.qkv, a + y.o, (float*)(a + y.lse), B, (int)c.H, N, 0.125f, s));
         TIC_TRY(tic_gemm_nt_bf16(a + y.o, lw + y.wo, M, D, D, TIC_EPI_RESID, lp + y.bo, nullptr, nullptr, hmid, hin, nullptr, nullptr, 0, s));
         TIC_TRY(tic_layernorm_fwd(hmid, D, lp + y.ln2_g, lp + y.ln2_b, a + y.a2, (float*)(a + y.mean2), (float*)(a + y.rstd2), M, D, c.eps, s));
-        TIC_TRY(tic_gemm_nt_bf16(a + y.a2, lw + y.w1, M, F, D, TIC_EPI_GELU, lp + y.b1, a + y.u, a + y.g, nullptr, nullptr, nullptr, nullptr, 0, s));
+        TIC_TRY(tic_gemm_nt_bf16(a + y.a2, lw + y.w1, M, F, D, TIC_EPI_GELU_DG, lp + y.b1, a + y.u, a + y.g, nullptr, nullptr, nullptr, nullptr, 0, s));
         TIC_TRY(tic_gemm_nt_bf16(a + y.g, lw + y.w2, M, D, F, TIC_EPI_RESID, lp + y.b2, nullptr, nullptr, hout, hmid, nullptr, nullptr, 0, s));
     }
     float* hL = (float*)(c.ws + y.hs + c.L * y.hs_stride);
@@ -685,7 +694,7 @@ extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stre
     // dX chain first (MLP, then attention); the four weight gradients of the block go out as ONE grouped launch
     // bias gradients ride on the producers of each dY: b1 <- DGELU epilogue, bo <- LN2 backward, bqkv <- attention
     // backward, b2 (of the layer below) <- LN1 backward; b2 of THIS layer was added by the producer of dhb
-    TIC_TRY(tic_gemm_nt_bf16_ex(dhb, lt + y.t_w2, M, F, D, TIC_EPI_DGELU, nullptr, du, nullptr, nullptr, nullptr, a + y.u, nullptr, 0, lg + y.b1, s));
+    TIC_TRY(tic_gemm_nt_bf16_ex(dhb, lt + y.t_w2, M, F, D, TIC_EPI_MULAUX, nullptr, du, nullptr, nullptr, nullptr, a + y.u, nullptr, 0, lg + y.b1, s));
     TIC_TRY(tic_gemm_nt_bf16(du, lt + y.t_w1, M, D, F, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
     TIC_TRY(tic_layernorm_bwd_ex(da, (float*)(a + y.hmid), D, lp + y.ln2_g, (float*)(a + y.mean2), (float*)(a + y.rstd2), dh, dh, dhb2, lg + y.ln2_g,
                                  lg + y.ln2_b, lg + y.bo, M, D, s));

@@ -107,6 +107,7 @@ TIC_DEV uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v);
 TIC_DEV void atomic_addf(float* p, float v) { atomicAdd(p, v); }
 TIC_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; exp2(-inf) = 0
 TIC_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
+TIC_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32 (1 ulp), not the 10-instruction IEEE divide
 
 #define TIC_TID ((int)threadIdx.x)
 #define TIC_BID_X ((int)blockIdx.x)
@@ -146,7 +147,7 @@ struct GeluParts {
 };
 TIC_DEV GeluParts gelu_parts(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = 1.0f / (1.0f + 0.3275911f * z);
+    const float t = fast_rcp(1.0f + 0.3275911f * z);
     const float e = fast_exp2(x * x * -0.72134752044448170f);   // exp(-x^2/2) = 2^(-x^2 * log2(e) / 2)
     float poly = 1.061405429f;
     poly = poly * t + -1.453152027f;
@@ -160,6 +161,29 @@ TIC_DEV GeluParts gelu_parts(float x) {
     return r;
 }
 TIC_DEV float gelu_erf(float x) { return x * gelu_parts(x).cdf; }
+// gelu and gelu' of a PAIR of values from one shared evaluation, written on 2-vectors so the multiply-adds
+// issue as v_pk_fma_f32 / v_pk_mul_f32 (two fp32 lanes per VALU slot): ~12 VALU slots + 2 transcendentals per element.
+struct GeluPair {
+    f32x2 g, dg;
+};
+TIC_DEV GeluPair gelu_pair(f32x2 x) {
+    const f32x2 a = f32x2{fabsf(x[0]), fabsf(x[1])};
+    const f32x2 den = a * 0.23164188f + 1.0f;                         // 1 + 0.3275911 |x| / sqrt 2
+    const f32x2 t = f32x2{fast_rcp(den[0]), fast_rcp(den[1])};
+    const f32x2 xe = x * x * -0.72134752044448170f;
+    const f32x2 e = f32x2{fast_exp2(xe[0]), fast_exp2(xe[1])};      // exp(-x^2 / 2)
+    f32x2 poly = t * 0.5307027145f + -0.7265760135f;                  // A&S 7.1.26 coefficients, halved
+    poly = poly * t + 0.7107068705f;
+    poly = poly * t + -0.142248368f;
+    poly = poly * t + 0.127414796f;
+    const f32x2 h = poly * t * e;                                     // 0.5 erfc(|x| / sqrt 2)
+    const f32x2 up = 1.0f - h;
+    const f32x2 cdf = f32x2{x[0] < 0.f ? h[0] : up[0], x[1] < 0.f ? h[1] : up[1]};
+    GeluPair r;
+    r.g = x * cdf;
+    r.dg = x * 0.39894228040143268f * e + cdf;
+    return r;
+}
 TIC_DEV float gelu_erf_grad(float x) {
     const GeluParts g = gelu_parts(x);
     return g.cdf + x * 0.39894228040143268f * g.e;
