@@ -62,7 +62,7 @@ def check_gemm_nt_gelu_resid_dgelu_patch(env, N=128, K=128, imgs=3, Pn=50):
     torch.testing.assert_close(dg5.float(), u64.grad.float(), atol=5e-3, rtol=8e-3)   # bf16 rounding of gelu'
     d6, cs6 = torch.empty(M, N, dtype=torch.bfloat16, device=dev), torch.zeros(N, device=dev)
     call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), M, N, K, 6, None, ptr(d6), None, None, None, ptr(dg5), None, 0, ptr(cs6), None)
-    torch.testing.assert_close(d6.float(), bfr(bfr(A.float() @ B.float().t()) * dg5.float()), atol=2e-3, rtol=8e-3)
+    torch.testing.assert_close(d6.float(), bfr(bfr(A.float() @ B.float().t()) * dg5.float()), atol=2e-3, rtol=1.6e-2)   # two bf16 ulps: the reference product rounds too
     torch.testing.assert_close(d6.float(), uu.grad, atol=0.03, rtol=0.03)
     torch.testing.assert_close(cs6, d6.float().sum(0), atol=0.05, rtol=0.02)
     # patch epilogue: M = images * patches, rows remapped past the CLS slot
