@@ -33,6 +33,7 @@
 
 #define G256_BUF_BYTES 65536u   // A 32 KiB + B 32 KiB
 #define G256_LDS_BYTES (2u * G256_BUF_BYTES)
+#define G256_NT_LDS_BYTES (G256_LDS_BYTES + 8192u)   // + [8 waves][256] fp32 column-sum partials of the staged epilogue
 
 TIC_DEV void g256_barrier() {
 #ifndef TIC_SIM
@@ -42,6 +43,156 @@ TIC_DEV void g256_barrier() {
 #ifndef TIC_SIM
     asm volatile("" ::: "memory");
 #endif
+}
+
+// ---- staged epilogue ------------------------------------------------------------------------------------------
+// Every epilogue starts from u = bf16(acc + bias).  The MFMA accumulator layout gives a lane 4 consecutive columns of
+// 16 different rows per store -- 32-byte pieces of 16 rows, and extra operands (residual / saved derivative) fetched
+// in the same shape, one latency-bound row at a time.  Here the block instead parks the bf16 tile in the LDS the main
+// loop has just released (256 x 256 x 2 B = the whole 128 KiB), which frees the 128 accumulator registers, and walks
+// it again row-contiguously: a wave touches whole 512 B (bf16) / 1 KiB (fp32) row segments per instruction, and the
+// extra operands of PF rows are in flight while the previous PF rows are computed and stored.
+// LDS layout: row stride 512 B; the 8-byte chunk index c8 (0..63) is XORed with (row & 15) << 2, so the 16 rows a
+// staging write covers land in 16 different 32-byte groups and a row read back stays one permuted 512 B line.
+TIC_DEV uint32_t g256_stage_off(int row, int c8) { return (uint32_t)row * 512u + (uint32_t)((c8 ^ ((row & 15) << 2)) * 8); }
+TIC_DEV float bf_lo(uint32_t u) {
+    union { uint32_t i; float f; } x;
+    x.i = u << 16;
+    return x.f;
+}
+TIC_DEV float bf_hi(uint32_t u) {
+    union { uint32_t i; float f; } x;
+    x.i = u & 0xffff0000u;
+    return x.f;
+}
+
+// 8 columns per thread: the bf16-output epilogues.  c16 = tid & 31, rows (tid >> 5) + 16 k.
+template <int EPI>
+TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
+    constexpr bool HAS_AUX = (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
+    constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
+    constexpr int PF = 4;
+    const int tid = TIC_TID, c16 = tid & 31, rsub = tid >> 5;
+    const int n = n0 + c16 * 8;
+    const uint32_t lds0 = (uint32_t)rsub * 512u + (uint32_t)(((c16 * 2) ^ (rsub << 2)) * 8);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    u32x4 aux[2][PF];
+    auto fetch = [&](int b) {
+        if (HAS_AUX) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int m = m0 + (b * PF + i) * 16 + rsub;
+                aux[b & 1][i] = (m < p.M) ? *reinterpret_cast<const u32x4*>(p.aux + (size_t)m * p.N + n) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int b = 0; b < 16 / PF; ++b) {
+        if (b + 1 < 16 / PF) fetch(b + 1);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int k = b * PF + i;
+            const int m = m0 + k * 16 + rsub;
+            const u32x4 u = __builtin_bit_cast(u32x4, lds_ld128(lds0 + (uint32_t)k * 8192u));
+            if (m >= p.M) continue;
+            const size_t o = (size_t)m * p.N + n;
+            if (EPI == TIC_EPI_BF16) {
+                *reinterpret_cast<u32x4*>(p.out + o) = u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cs[2 * j] += bf_lo(u[j]);
+                    cs[2 * j + 1] += bf_hi(u[j]);
+                }
+            } else if (EPI == TIC_EPI_GELU) {
+                u32x4 g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = pack2bf(gelu_erf(bf_lo(u[j])), gelu_erf(bf_hi(u[j])));
+                *reinterpret_cast<u32x4*>(p.out + o) = u;
+                *reinterpret_cast<u32x4*>(p.out2 + o) = g;
+            } else if (EPI == TIC_EPI_GELU_DG) {
+                u32x4 g, dg;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const GeluPair r = gelu_pair(f32x2{bf_lo(u[j]), bf_hi(u[j])});
+                    g[j] = pack2bf(r.g[0], r.g[1]);
+                    dg[j] = pack2bf(r.dg[0], r.dg[1]);
+                }
+                *reinterpret_cast<u32x4*>(p.out + o) = dg;
+                *reinterpret_cast<u32x4*>(p.out2 + o) = g;
+            } else {   // DGELU / MULAUX
+                const u32x4 a = aux[b & 1][i];
+                u32x4 d;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float f0 = (EPI == TIC_EPI_DGELU) ? gelu_erf_grad(bf_lo(a[j])) : bf_lo(a[j]);
+                    const float f1 = (EPI == TIC_EPI_DGELU) ? gelu_erf_grad(bf_hi(a[j])) : bf_hi(a[j]);
+                    const float d0 = bf_lo(u[j]) * f0, d1 = bf_hi(u[j]) * f1;
+                    d[j] = pack2bf(d0, d1);
+                    cs[2 * j] += d0;
+                    cs[2 * j + 1] += d1;
+                }
+                *reinterpret_cast<u32x4*>(p.out + o) = d;
+            }
+        }
+    }
+    // fused bias gradient: lanes l, l^32 hold the other rows of the same 8 columns; the 8 waves meet in LDS and 256
+    // threads add one contiguous fp32 row to the global vector
+    if (HAS_COLSUM && p.colsum) {   // kernel-argument condition: block-uniform
+        const int l = tid & 63, w = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            cs[j] += shfl_xor(cs[j], 32);
+            if (l < 32) lds_stf(G256_LDS_BYTES + (uint32_t)(w * 256 + c16 * 8 + j) * 4u, cs[j]);
+        }
+        block_sync();
+        if (tid < 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) t += lds_ldf(G256_LDS_BYTES + (uint32_t)(ww * 256 + tid) * 4u);
+            atomic_addf(p.colsum + n0 + tid, t);
+        }
+    }
+}
+
+// 4 columns per thread: the fp32-output epilogues (RESID, PATCH).  c8 = tid & 63, rows (tid >> 6) + 8 k.
+template <int EPI>
+TIC_DEV void g256_finish_f32(const GemmNtParams& p, int m0, int n0) {
+    constexpr int PF = 4;
+    const int tid = TIC_TID, c8 = tid & 63, rsub = tid >> 6;
+    const int n = n0 + c8 * 4;
+    f32x4 ex[2][PF];
+    auto src_of = [&](int m) -> const float* {
+        if (EPI == TIC_EPI_RESID) return p.resid + (size_t)m * p.N + n;
+        return p.rowtab + (size_t)(1 + m % p.patches) * p.N + n;
+    };
+    auto fetch = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int m = m0 + (b * PF + i) * 8 + rsub;
+            ex[b & 1][i] = (m < p.M) ? *reinterpret_cast<const f32x4*>(src_of(m)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int b = 0; b < 32 / PF; ++b) {
+        if (b + 1 < 32 / PF) fetch(b + 1);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int k = b * PF + i;
+            const int row = k * 8 + rsub, m = m0 + row;
+            const u32x2 u = __builtin_bit_cast(u32x2, lds_ld64(g256_stage_off(row, c8)));
+            if (m >= p.M) continue;
+            const f32x4 e = ex[b & 1][i];
+            const f32x4 y = f32x4{bf_lo(u[0]) + e[0], bf_hi(u[0]) + e[1], bf_lo(u[1]) + e[2], bf_hi(u[1]) + e[3]};
+            size_t orow = (size_t)m;
+            if (EPI == TIC_EPI_PATCH) {
+                const int img = m / p.patches;
+                orow = (size_t)img * (p.patches + 1) + 1 + (m - img * p.patches);
+            }
+            *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.N + n) = y;
+        }
+    }
 }
 
 template <int EPI>
@@ -167,12 +318,26 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         mma(1, 0, fb0);
         g256_barrier();
     }
-    wait_vmcnt0();   // drain the zero fills issued for the tiles past the end before LDS is released
+    wait_vmcnt0();   // drain the zero fills issued for the tiles past the end before LDS is reused
     if (wr == 0) g256_barrier();   // re-balance the stagger
+    g256_barrier();                // every wave's LDS reads and DMA writes have retired: the tile buffers are free
 
-    // rows r = i*4 + mt, column groups g = j*2 + nt
-    gemm_epilogue<EPI, 8, 4>(
-        p, [&](int r) { return m0 + (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (l & 15); },
-        [&](int g) { return n0 + (g >> 1) * 128 + wc * 32 + (g & 1) * 16 + 4 * (l >> 4); },
-        [&](int r, int g) { return acc[r >> 2][g >> 1][r & 3][g & 1]; });
+    // ---- stage u = bf16(acc + bias) into LDS: rows r = i*4 + mt, column groups g = j*2 + nt
+    constexpr bool HAS_BIAS = (EPI != TIC_EPI_DGELU && EPI != TIC_EPI_MULAUX);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = (g >> 1) * 128 + wc * 32 + (g & 1) * 16 + 4 * (l >> 4);
+        const f32x4 bias = (HAS_BIAS && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (l & 15);
+            const f32x4 v = acc[r >> 2][g >> 1][r & 3][g & 1] + bias;
+            lds_st64(g256_stage_off(row, col >> 2), __builtin_bit_cast(bf16x4, u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])}));
+        }
+    }
+    block_sync();
+    if (EPI == TIC_EPI_RESID || EPI == TIC_EPI_PATCH)
+        g256_finish_f32<EPI>(p, m0, n0);
+    else
+        g256_finish_bf16<EPI>(p, m0, n0);
 }

@@ -98,8 +98,8 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
 #define TIC_GEMM_NT_LAUNCH(E)                                                                        \
     do {                                                                                             \
         if (big) {                                                                                   \
-            TIC_RT_MAX_LDS(gemm_nt256_kernel<E>, G256_LDS_BYTES);                                    \
-            TIC_LAUNCH(gemm_nt256_kernel<E>, grid, 512, G256_LDS_BYTES, stream, p);                  \
+            TIC_RT_MAX_LDS(gemm_nt256_kernel<E>, G256_NT_LDS_BYTES);                                 \
+            TIC_LAUNCH(gemm_nt256_kernel<E>, grid, 512, G256_NT_LDS_BYTES, stream, p);               \
         } else {                                                                                     \
             TIC_RT_MAX_LDS(gemm_nt_kernel<E>, GEMM_LDS_BYTES);                                       \
             TIC_LAUNCH(gemm_nt_kernel<E>, grid, 256, GEMM_LDS_BYTES, stream, p);                     \
