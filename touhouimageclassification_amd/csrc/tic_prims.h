@@ -133,7 +133,14 @@ TIC_DEV bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 TIC_DEV float bfround(float f) { return bf2f(f2bf(f)); }
+#ifdef TIC_SIM
 TIC_DEV uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+#else
+typedef __attribute__((ext_vector_type(2))) __bf16 tic_bf16x2_t;
+TIC_DEV uint32_t pack2bf(float lo, float hi) {   // ONE v_cvt_pk_bf16_f32 (two scalar casts cost two converts and an SDWA or)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, tic_bf16x2_t));
+}
+#endif
 
 // exact-erf GELU (HF activations.py:83) and its derivative, with erfc evaluated by the
 // Abramowitz-Stegun 7.1.26 rational form: erfc(z) = P(t) exp(-z^2), t = 1/(1 + 0.3275911 z), z >= 0,
