@@ -7,27 +7,35 @@
 // 64x32 quadrants Q(i,j): rows i*128 + wr*64 + [0,64), columns j*128 + wc*32 + [0,32) -- interleaved so
 // that quadrant (i,j) needs only A half-tile i and B half-tile j (a half-tile = 128 rows x 64 k = 16 KiB =
 // 2 LDS-DMA pieces per thread).  One K tile = 4 phases in the order Q00, Q01, Q11, Q10; a phase is
-//     load segment : ds_read the newly needed operand sub-tile (A0+B0 | B1 | A1 | B0), issue the LDS-DMA of
-//                    ONE half-tile of the NEXT K tile (A0 | B0 | B1 | A1), counted s_waitcnt vmcnt
+//     load segment : issue the LDS-DMA of ONE half-tile (2 pieces per wave), s_waitcnt vmcnt(8)
 //     s_barrier
-//     MFMA segment : 16 x v_mfma_f32_16x16x32_bf16 (64x32 quadrant, K = 64)
+//     MFMA segment : 16 x v_mfma_f32_16x16x32_bf16 (64x32 quadrant, K = 64) with the ds_reads of the NEXT phase's
+//                    fragments slotted into the MFMA gaps, s_waitcnt lgkmcnt(0)
 //     s_barrier
 // The two wave groups (wr = 0 / 1 -- the two waves that share each SIMD) run ONE barrier apart, so one
-// group's MFMA segment overlaps the other's load segment (matrix beside memory on every SIMD).
-// LDS-DMA stays in flight across barriers (raw s_barrier, never __syncthreads).  Prefetch is 5-6 phases
-// deep inside the two K-tile buffers: the B0 fragments stay in registers for the whole tile, so every
-// half-tile slot is read in exactly one phase and is re-filled as soon as that read has retired:
-//     tile t phase 0: issue B1(t+1)   phase 1: A1(t+1)   phase 2: A0(t+2)   phase 3: B0(t+2)
-// i.e. A0/B0 of tile t+2 go into the buffer tile t is still being computed from.  vmcnt(8) at phases
-// 3, 0, 1 leaves four half-tiles (64 KiB per CU) in flight.  K tiles past the end are issued with an
-// out-of-range offset (the hardware range check turns them into zero fills with no memory traffic) so
-// the steady-state body and its vmcnt counts are the same for every tile.
-// Hazard bookkeeping (interval = time between consecutive barriers; group 0 runs its load segment of
-// global phase P in interval 2P, group 1 in 2P+1):
-//   RAW  a half-tile read in phase P is waited for (by every wave that issued a piece of it) in the load
-//        segment of phase P-1, i.e. no later than interval 2P-1, and read from interval 2P on;
-//   WAR  a slot is re-filled >= 2 phases after its only read (A0: read ph 0 -> filled ph 2; B0: ph 0 -> ph 3;
-//        B1: ph 1 -> next ph 0; A1: ph 2 -> next ph 1).
+// group's MFMA segment overlaps the other's load segment.  Measured with parts of the loop compiled out
+// (tools/gemm_dbg.py, M 32702 N K 4096): MFMA alone 506 us, LDS-DMA alone 553 us, fragment reads alone 265 us -- but
+// with the reads in the LOAD segment (next to the DMA issue, 100-185 cycles per piece) that segment outlasted
+// the other group's 256-cycle MFMA segment and the three together took 814 us; moving the reads under the MFMAs
+// leaves the load segment with the DMA issue and the counted wait only.
+// LDS-DMA stays in flight across barriers (raw s_barrier, never __syncthreads).  Every load segment issues one
+// half-tile and waits for the one issued four phases earlier (4 half-tiles = 64 KiB per CU always in flight):
+//     tile t phase 0: issue A1(t+1)   phase 1: B0(t+2)   phase 2: A0(t+2)   phase 3: B1(t+2)
+//     MFMA segment of phase 0 reads A0(t) k-half 1 + B1(t), phase 1: A1(t) k-half 0, phase 2: A1(t) k-half 1,
+//     phase 3: A0(t+1) k-half 0 + B0(t+1)   (B0 stays in registers from phase 0 to phase 3; fragment peak 80 VGPRs)
+// K tiles past the end are issued with an out-of-range offset (the hardware range check turns them into zero
+// fills with no memory traffic) so the steady-state body and its vmcnt counts are the same for every tile.
+// Hazard bookkeeping (interval = time between consecutive barriers; group 0 runs the load segment LS(P) of global
+// phase P in interval 2P and its MFMA segment MS(P) in 2P+1, group 1 one interval later):
+//   RAW  a half-tile read in MS(q) (group 0: interval 2q+1) must have been waited for by EVERY wave that issued a
+//        piece of it no later than interval 2q, i.e. in LS(q-1) (group 1's LS(q-1) is interval 2q-1).  With
+//        vmcnt(8) the half-tile issued in LS(p-4) is complete in LS(p):
+//          B1(t): issued LS(4t-5), complete LS(4t-1), read MS(4t)      A1(t): LS(4t-4) / LS(4t) / MS(4t+1), MS(4t+2)
+//          B0(t+1): LS(4t-3) / LS(4t+1) / MS(4t+3)                      A0(t+1): LS(4t-2) / LS(4t+2) / MS(4t+3), MS(4t+4)
+//   WAR  reads issued in MS(q) are retired (lgkmcnt(0)) before that segment's closing barrier, by both groups no
+//        later than interval 2q+2; the slot may be re-filled from LS(q+2) on (group 0: interval 2q+4):
+//          A0 slot: last read MS(4t), refilled LS(4t+2)     B0: MS(4t-1) -> LS(4t+1)
+//          B1 slot: read MS(4t),      refilled LS(4t+3)     A1: last read MS(4t+2) -> LS(4t+4)
 #pragma once
 #include "gemm.h"
 
@@ -195,7 +203,9 @@ TIC_DEV void g256_finish_f32(const GemmNtParams& p, int m0, int n0) {
     }
 }
 
-template <int EPI>
+// DBG (measurement builds only, EPI_BF16): bit 0 = no LDS-DMA, bit 1 = no fragment ds_reads, bit 2 = no MFMA -- isolates which
+// of the three pipes bounds the main loop (tic_set_option("gemm_dbg")); results are garbage by construction.
+template <int EPI, int DBG = 0>
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wr = w >> 2, wc = w & 3;
@@ -208,30 +218,23 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
 
     // ---- LDS-DMA: half-tile h of operand X = 16 one-KiB pieces (8 rows each); this wave moves pieces 2w, 2w+1
     const uint32_t slot_log = (uint32_t)(l & 7) ^ ((((uint32_t)l >> 4) & 3u) << 1);
-    uint32_t voa[2][2], vob[2][2];   // [half][piece]
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = h * 128 + (2 * w + j) * 8 + (l >> 3);
-            voa[h][j] = (uint32_t)(((size_t)(m0 + r) * p.K + slot_log * 8) * 2);
-            vob[h][j] = (uint32_t)(((size_t)(n0 + r) * p.K + slot_log * 8) * 2);
-        }
+    // ONE long-lived offset VGPR per operand (piece 0 of half 0); the other pieces add a wave-uniform row distance when
+    // they are issued.  The row stays in the VGPR offset because only that offset is range-checked (rows >= M read 0).
+    const uint32_t voa0 = (uint32_t)(((size_t)(m0 + 2 * w * 8 + (l >> 3)) * p.K + slot_log * 8) * 2);
+    const uint32_t vob0 = (uint32_t)(((size_t)(n0 + 2 * w * 8 + (l >> 3)) * p.K + slot_log * 8) * 2);
+    const uint32_t row8 = (uint32_t)p.K * 16u;   // 8 rows in bytes
     // which: 0 = A0, 1 = B0, 2 = B1, 3 = A1.  K tiles >= nk become zero fills (see header).
     const int nk = p.K / 64;
     auto issue = [&](int buf, int kt, int which) {
-        const uint32_t soff = (uint32_t)kt * 128u;
+        if (DBG & 1) return;
         const bool isA = (which == 0 || which == 3);
         const int h = (which >= 2) ? 1 : 0;
         const bool live = kt < nk;
+        const uint32_t soff = live ? (uint32_t)kt * 128u : 0u;
         const uint32_t base = (uint32_t)buf * G256_BUF_BYTES + (isA ? 0u : 32768u) + (uint32_t)h * 16384u + (uint32_t)(2 * w) * 1024u;
-        if (isA) {
-            glds16(ra, base, live ? voa[h][0] : 0xFFFFFFF0u, live ? soff : 0u);
-            glds16(ra, base + 1024u, live ? voa[h][1] : 0xFFFFFFF0u, live ? soff : 0u);
-        } else {
-            glds16(rb, base, live ? vob[h][0] : 0xFFFFFFF0u, live ? soff : 0u);
-            glds16(rb, base + 1024u, live ? vob[h][1] : 0xFFFFFFF0u, live ? soff : 0u);
-        }
+        const uint32_t v0 = (isA ? voa0 : vob0) + (uint32_t)h * 16u * row8;
+        glds16(isA ? ra : rb, base, live ? v0 : 0xFFFFFFF0u, soff);
+        glds16(isA ? ra : rb, base + 1024u, live ? v0 + row8 : 0xFFFFFFF0u, soff);
     };
 
     // ---- fragment offsets inside a buffer ----------------------------------------------------------------
@@ -241,101 +244,171 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     for (int ks = 0; ks < 2; ++ks) fo[ks] = (uint32_t)(l & 15) * 128u + ((((uint32_t)ks * 4 + ((uint32_t)l >> 4)) ^ sw) * 16u);
     const uint32_t a_row0 = (uint32_t)wr * 64, b_row0 = (uint32_t)wc * 32;
 
+    // accumulators start at the bias of their columns (u = bf16(bias + sum): the add costs nothing and no bias
+    // registers live through the loop or the staging pass)
+    // (the host passes bias = nullptr for the epilogues that have none: DGELU / MULAUX)
     f32x4 acc[2][2][4][2];   // [i][j][mt][nt]
+    float zero_v = 0.f;
+#ifndef TIC_SIM
+    asm volatile("" : "+v"(zero_v));   // opaque zero: a literal 0 makes hipcc peel the first K tile (C = 0 MFMA forms) and spill
+#endif
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + j * 128 + wc * 32 + nt * 16 + 4 * (l >> 4);
+            f32x4 b4 = f32x4{zero_v, zero_v, zero_v, zero_v};
+            if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];   // [mt][ks], [nt][ks]; B0 fragments live for the whole K tile
+                for (int mt = 0; mt < 4; ++mt) acc[i][j][mt][nt] = b4;
+        }
+    // fragment registers: A0 / A1 of the current tile and two B sets whose roles (B0 | B1) swap every K tile
+    bf16x8 fa0[4][2], fa1[4][2], fbx[2][2], fby[2][2];   // [mt][ks], [nt][ks]
+    if (DBG & 2) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            fa0[x][0] = fa0[x][1] = fa1[x][0] = fa1[x][1] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+            fbx[x & 1][x >> 1] = fby[x & 1][x >> 1] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+        }
+    }
 
-    auto load_a = [&](uint32_t bufb, int i) {
+    auto load_a = [&](uint32_t bufb, int i, bf16x8 (&fa)[4][2], int ks) {   // one k-half (32 of the 64 k) of an A half-tile
+        if (DBG & 2) return;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[mt][ks] = lds_ld128(bufb + ((uint32_t)i * 128 + a_row0 + (uint32_t)mt * 16) * 128u + fo[ks]);
+        for (int mt = 0; mt < 4; ++mt) fa[mt][ks] = lds_ld128(bufb + ((uint32_t)i * 128 + a_row0 + (uint32_t)mt * 16) * 128u + fo[ks]);
     };
     auto load_b = [&](uint32_t bufb, int j, bf16x8 (&fb)[2][2]) {
+        if (DBG & 2) return;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) fb[nt][ks] = lds_ld128(bufb + 32768u + ((uint32_t)j * 128 + b_row0 + (uint32_t)nt * 16) * 128u + fo[ks]);
     };
-    auto mma = [&](int i, int j, const bf16x8 (&fb)[2][2]) {
-        prio_hi();
+    auto mma = [&](int i, int j, const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2]) {
+        if (DBG & 4) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[i][j][mt][0][0] += (float)fa[mt][0][0] + (float)fb[0][0][1];   // keep the reads alive
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = mfma16(fb[nt][ks], fa[mt][ks], acc[i][j][mt][nt]);
+    };
+    // MFMA segment = 16 MFMAs with the NEXT phase's NR fragment reads slotted one per MFMA gap (the reads ride in the
+    // shadow of the matrix pipe instead of lengthening the load segment), retired before the closing barrier.
+#ifdef TIC_SIM
+#define G256_INTERLEAVE(NR) do { } while (0)
+#else
+#define G256_INTERLEAVE(NR)                                              \
+    do {                                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < (NR); ++q_) {            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           \
+        }                                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16 - (NR), 0);       \
+    } while (0)
+#endif
+    // one K tile; on entry B0(t) is in fbp and the first k-half of A0(t) in fa0[.][0]; on exit the same for t+1 with fbq.
+    // Phase p: load segment {issue one half-tile, vmcnt(8): the half-tile issued 4 phases ago has landed} | barrier |
+    // MFMA segment {16 MFMA (k-half 0 first) + the fragment reads listed} | lgkmcnt(0), barrier.  A fragments arrive one
+    // k-half at a time (the second half at the start of the segment that consumes it, under its first 8 MFMAs): the
+    // peak is 80 fragment registers, which is what fits beside 128 accumulators in the 256 registers of a wave.
+    auto tile = [&](int kt, bf16x8 (&fbp)[2][2], bf16x8 (&fbq)[2][2]) {
+        const int cur = kt & 1;
+        const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES, bufn = (uint32_t)(cur ^ 1) * G256_BUF_BYTES;
+        // ---- phase 0: Q00 = A0 x B0 ; reads A0(t) k-half 1, B1(t)
+        issue(cur ^ 1, kt + 1, 3);   // A1(t+1): that slot was last read in phase 2 of tile t-1
+        wait_vmcnt<8>();             // A1(t) has landed (first read: phase 1)
+        g256_barrier();
+        prio_hi();
+        load_a(bufb, 0, fa0, 1);
+        load_b(bufb, 1, fbq);
+        mma(0, 0, fa0, fbp);
+        G256_INTERLEAVE(8);
         prio_lo();
+        wait_lgkmcnt0();
+        g256_barrier();
+        // ---- phase 1: Q01 = A0 x B1 ; reads A1(t) k-half 0
+        issue(cur, kt + 2, 1);       // B0(t+2): B0(t) was read in phase 3 of tile t-1 (and lives in fbp)
+        wait_vmcnt<8>();             // B0(t+1) has landed (read: phase 3)
+        g256_barrier();
+        prio_hi();
+        load_a(bufb, 1, fa1, 0);
+        mma(0, 1, fa0, fbq);
+        G256_INTERLEAVE(4);
+        prio_lo();
+        wait_lgkmcnt0();
+        g256_barrier();
+        // ---- phase 2: Q11 = A1 x B1 ; reads A1(t) k-half 1
+        issue(cur, kt + 2, 0);       // A0(t+2): A0(t) was last read in phase 0
+        wait_vmcnt<8>();             // A0(t+1) has landed (first read: phase 3)
+        g256_barrier();
+        prio_hi();
+        load_a(bufb, 1, fa1, 1);
+        mma(1, 1, fa1, fbq);
+        G256_INTERLEAVE(4);
+        prio_lo();
+        wait_lgkmcnt0();
+        g256_barrier();
+        // ---- phase 3: Q10 = A1 x B0 ; reads A0(t+1) k-half 0, B0(t+1)
+        issue(cur, kt + 2, 2);       // B1(t+2): B1(t) was read in phase 0
+        wait_vmcnt<8>();             // B1(t+1) has landed (read: phase 0 of tile t+1)
+        g256_barrier();
+        prio_hi();
+        load_a(bufn, 0, fa0, 0);
+        load_b(bufn, 0, fbq);
+        mma(1, 0, fa1, fbp);
+        G256_INTERLEAVE(8);
+        prio_lo();
+        wait_lgkmcnt0();
+        g256_barrier();
     };
 
-    // prologue: K tile 0 completely + A0, B0 of tile 1; wait for A0(0), B0(0); group 1 then falls one barrier behind
-    issue(0, 0, 0);
+    // prologue: all of K tile 0 and B0, A0, B1 of tile 1 (7 of the 8 half-tile slots) in the steady-state issue order
+    // B0, A0, B1, A1; B0(0), A0(0), B1(0) landed; the first fragments are read here, then group 1 falls one barrier behind
     issue(0, 0, 1);
+    issue(0, 0, 0);
     issue(0, 0, 2);
     issue(0, 0, 3);
-    issue(1, 1, 0);
     issue(1, 1, 1);
+    issue(1, 1, 0);
+    issue(1, 1, 2);
     wait_vmcnt<8>();
     g256_barrier();
+    load_a(0u, 0, fa0, 0);
+    load_b(0u, 0, fbx);
+    wait_lgkmcnt0();
     if (wr == 1) g256_barrier();
 
+    // two tiles per trip (the B register sets swap roles every tile); an odd tile count runs one extra all-zero tile
+    // (its DMAs are the zero fills above) rather than a second loop exit, which made hipcc copy all 128 accumulators
 #pragma nounroll
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES;
-        // ---- phase 0: Q00 (A0, B0 landed: waited for in phase 3 of the previous tile / prologue)
-        load_a(bufb, 0);
-        load_b(bufb, 0, fb0);
-        issue(cur ^ 1, kt + 1, 2);   // B1(t+1)
-        wait_vmcnt<8>();             // B1(t) has landed
-        g256_barrier();
-        mma(0, 0, fb0);
-        g256_barrier();
-        // ---- phase 1: Q01
-        load_b(bufb, 1, fb1);
-        issue(cur ^ 1, kt + 1, 3);   // A1(t+1)
-        wait_vmcnt<8>();             // A1(t) has landed
-        g256_barrier();
-        mma(0, 1, fb1);
-        g256_barrier();
-        // ---- phase 2: Q11
-        load_a(bufb, 1);
-        issue(cur, kt + 2, 0);       // A0(t+2) into THIS buffer: its A0 slot was last read in phase 0
-        g256_barrier();
-        mma(1, 1, fb1);
-        g256_barrier();
-        // ---- phase 3: Q10 (B0 fragments still in registers: no LDS read)
-        issue(cur, kt + 2, 1);       // B0(t+2)
-        wait_vmcnt<8>();             // A0(t+1), B0(t+1) have landed
-        g256_barrier();
-        mma(1, 0, fb0);
-        g256_barrier();
+    for (int kt = 0; kt < nk; kt += 2) {
+        tile(kt, fbx, fby);
+        tile(kt + 1, fby, fbx);
     }
     wait_vmcnt0();   // drain the zero fills issued for the tiles past the end before LDS is reused
     if (wr == 0) g256_barrier();   // re-balance the stagger
     g256_barrier();                // every wave's LDS reads and DMA writes have retired: the tile buffers are free
 
-    // ---- stage u = bf16(acc + bias) into LDS: rows r = i*4 + mt, column groups g = j*2 + nt
-    constexpr bool HAS_BIAS = (EPI != TIC_EPI_DGELU && EPI != TIC_EPI_MULAUX);
+    // ---- stage u = bf16(acc) into LDS: rows r = i*4 + mt, column groups g = j*2 + nt
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int col = (g >> 1) * 128 + wc * 32 + (g & 1) * 16 + 4 * (l >> 4);
-        const f32x4 bias = (HAS_BIAS && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n0 + col) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int row = (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (l & 15);
-            const f32x4 v = acc[r >> 2][g >> 1][r & 3][g & 1] + bias;
+            const f32x4 v = acc[r >> 2][g >> 1][r & 3][g & 1];
             lds_st64(g256_stage_off(row, col >> 2), __builtin_bit_cast(bf16x4, u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])}));
         }
     }
     block_sync();
+    sched_fence();   // keep the second pass (and its operand prefetch) below the staging pass: the accumulators are dead from here
     if (EPI == TIC_EPI_RESID || EPI == TIC_EPI_PATCH)
         g256_finish_f32<EPI>(p, m0, n0);
     else

@@ -45,9 +45,14 @@ static int tic_after_launch(const char* what) {
 // tuning knobs (process-wide, for A/B measurements and tests): "gemm_tile" = 0 (auto) | 128 | 256 ;
 // "tn_streamk" = 1 (default: grouped dW as 256 equal stream-K shares) | 0 (one workgroup per full-M tile)
 static int g_opt_gemm_tile = 0;
+static int g_opt_gemm_dbg = 0;    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 extern "C" int tic_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "gemm_dbg") && value >= 0 && value < 8) {
+        g_opt_gemm_dbg = value;
+        return TIC_OK;
+    }
     if (name && !strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) {
         g_opt_gemm_tile = value;
         return TIC_OK;
@@ -89,7 +94,8 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
                 "gemm_nt: operand exceeds the 4 GiB buffer-resource range");
     GemmNtParams p;
     memset(&p, 0, sizeof(p));
-    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K;
+    p.bias = (epilogue == TIC_EPI_DGELU || epilogue == TIC_EPI_MULAUX) ? nullptr : bias;
     p.out = (bf16_t*)out_bf16; p.out2 = (bf16_t*)out2_bf16; p.out_f32 = out_f32; p.resid = resid;
     p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches; p.colsum = colsum;
     // big products go to the deep-pipelined 256x256 kernel (one block per CU), the rest to the 128x128 one
@@ -108,6 +114,18 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     switch (epilogue) {
         case TIC_EPI_BF16:
             TIC_REQUIRE(out_bf16, "gemm_nt: EPI_BF16 needs out_bf16");
+            if (big && g_opt_gemm_dbg) {
+#define TIC_DBG_CASE(D)                                                                                   \
+    case D:                                                                                               \
+        TIC_RT_MAX_LDS((gemm_nt256_kernel<TIC_EPI_BF16, D>), G256_NT_LDS_BYTES);                          \
+        TIC_LAUNCH((gemm_nt256_kernel<TIC_EPI_BF16, D>), grid, 512, G256_NT_LDS_BYTES, stream, p);        \
+        break;
+                switch (g_opt_gemm_dbg) {
+                    TIC_DBG_CASE(1) TIC_DBG_CASE(2) TIC_DBG_CASE(3) TIC_DBG_CASE(4) TIC_DBG_CASE(5) TIC_DBG_CASE(6) TIC_DBG_CASE(7)
+                }
+#undef TIC_DBG_CASE
+                break;
+            }
             TIC_GEMM_NT_LAUNCH(TIC_EPI_BF16);
             break;
         case TIC_EPI_GELU:
