@@ -52,9 +52,8 @@ TIC_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& tm, in
 }
 
 // ---- epilogue ---------------------------------------------------------------------------------------
-// A lane owns, per output row m, NG groups of 4 consecutive columns.  Bias is loaded ONCE per column group
-// into registers before any store (a load placed after a store to possibly-aliasing memory costs a full
-// vmcnt(0) round trip each time); the per-element extra operand (residual / pre-activation / position
+// A lane owns, per output row m, NG groups of 4 consecutive columns.  The bias is already inside the accumulators
+// (they start at it); the per-element extra operand (residual / pre-activation / position
 // row) is fetched one row AHEAD of its use, so the loads of row r+1 fly while row r is computed and stored.
 struct EpiExtra {
     f32x4 f;   // RESID: residual, PATCH: position-embedding row
@@ -74,9 +73,8 @@ TIC_DEV EpiExtra epi_fetch(const GemmNtParams& p, int m, int n) {
 }
 // returns the 4 values written (0 for masked rows / columns) so that callers can form column sums
 template <int EPI>
-TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias, EpiExtra e) {
+TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, EpiExtra e) {   // v = bias + sum (the accumulators start at the bias)
     if (m >= p.M || n >= p.N) return f32x4{0.f, 0.f, 0.f, 0.f};   // ragged M; N not a multiple of the tile (conv channels 64, C*k*k ...)
-    if (EPI != TIC_EPI_DGELU && EPI != TIC_EPI_MULAUX) v += bias;
     const size_t o = (size_t)m * p.N + n;
     if (EPI == TIC_EPI_BF16) {
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
@@ -124,10 +122,6 @@ TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, f32x4 bias
 // NR rows x NG column groups per lane; row_of(r) / col_of(g) give the global coordinates, acc_of(r, g) the value
 template <int EPI, int NR, int NG, class RowF, class ColF, class AccF>
 TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF acc_of) {
-    f32x4 bias[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-        bias[g] = (EPI != TIC_EPI_DGELU && EPI != TIC_EPI_MULAUX && p.bias && col_of(g) < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col_of(g)) : f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX || EPI == TIC_EPI_PATCH);
     constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
     EpiExtra ex[2][NG];
@@ -146,7 +140,7 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const f32x4 w4 = epi_store<EPI>(p, row_of(r), col_of(g), acc_of(r, g), bias[g], ex[r & 1][g]);
+            const f32x4 w4 = epi_store<EPI>(p, row_of(r), col_of(g), acc_of(r, g), ex[r & 1][g]);
             if (HAS_COLSUM) cs[g] += w4;
         }
     }
@@ -215,11 +209,15 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
     for (int ks = 0; ks < 2; ++ks) fo[ks] = (uint32_t)(l & 15) * 128u + ((((uint32_t)ks * 4 + ((uint32_t)l >> 4)) ^ sw) * 16u);
     const uint32_t a_base = (uint32_t)wm * 64 * 128, b_base = 16384u + (uint32_t)wn * 64 * 128;
 
+    // accumulators start at the bias of their columns (same summation order as gemm256.h: the two kernels agree bit for bit)
     f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + 4 * (l >> 4);
+        const f32x4 b4 = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) acc[i][j] = b4;
+    }
 
     const int nk = p.K / GEMM_BK;
     stage(0, 0);

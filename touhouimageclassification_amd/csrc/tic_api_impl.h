@@ -49,7 +49,7 @@ static int g_opt_gemm_dbg = 0;    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 extern "C" int tic_set_option(const char* name, int value) {
-    if (name && !strcmp(name, "gemm_dbg") && value >= 0 && value < 8) {
+    if (name && !strcmp(name, "gemm_dbg") && value >= 0 && value < 16) {
         g_opt_gemm_dbg = value;
         return TIC_OK;
     }
@@ -122,6 +122,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         break;
                 switch (g_opt_gemm_dbg) {
                     TIC_DBG_CASE(1) TIC_DBG_CASE(2) TIC_DBG_CASE(3) TIC_DBG_CASE(4) TIC_DBG_CASE(5) TIC_DBG_CASE(6) TIC_DBG_CASE(7)
+                    TIC_DBG_CASE(8) TIC_DBG_CASE(10) TIC_DBG_CASE(12) TIC_DBG_CASE(14)
                 }
 #undef TIC_DBG_CASE
                 break;
