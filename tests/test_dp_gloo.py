@@ -1,4 +1,4 @@
-"""Data-parallel path on CPU: world_size 2 over gloo, tiny model through the simulator backend.
+"""Data-parallel path on CPU: world_size 2 over gloo, micro model (32 px, 5 tokens) through the simulator backend.
 Two ranks x B images with bucketed SUM all-reduce (mean folded into the loss gradient) must produce the same
 gradients and the same AdamW update as one process on the concatenated 2B batch."""
 import os
@@ -27,12 +27,12 @@ def _worker(rank, world, port, out_dir):
     from touhouimageclassification_amd.optim import FusedAdamW
     from touhouimageclassification_amd.step import fused_train_step
     torch.manual_seed(100 + rank)   # replicas start DIFFERENT on purpose: broadcast must fix that
-    model = ViT(10, pretrained=False, model_name="tiny", backend=SimBackend())
+    model = ViT(10, pretrained=False, model_name="micro", backend=SimBackend())
     sync = BucketedGradSync(model)
     sync.broadcast_parameters()
     opt = FusedAdamW(model, lr=1e-3, weight_decay=0.01)
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(2 * world, 3, 224, 224, generator=g)
+    x = torch.randn(2 * world, 3, 32, 32, generator=g)
     y = torch.randint(0, 10, (2 * world,), generator=g)
     xs, ys = x[2 * rank:2 * rank + 2], y[2 * rank:2 * rank + 2]
     buckets = []
@@ -59,10 +59,10 @@ def test_two_rank_dp_matches_single_process(tmp_path):
     from touhouimageclassification_amd.optim import FusedAdamW
     from touhouimageclassification_amd.step import fused_train_step
     torch.manual_seed(100)
-    model = ViT(10, pretrained=False, model_name="tiny", backend=SimBackend())
+    model = ViT(10, pretrained=False, model_name="micro", backend=SimBackend())
     opt = FusedAdamW(model, lr=1e-3, weight_decay=0.01)
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(4, 3, 224, 224, generator=g)
+    x = torch.randn(4, 3, 32, 32, generator=g)
     y = torch.randint(0, 10, (4,), generator=g)
     loss, _ = fused_train_step(model, opt, x, y, None)
     ref = model._engine.grads

@@ -84,7 +84,7 @@ def test_cutmix_mixup_sampler():
 class _TinyFloatSet(torch.utils.data.Dataset):
     def __init__(self, n):
         g = torch.Generator().manual_seed(3)
-        self.x = torch.randn(n, 3, 224, 224, generator=g)
+        self.x = torch.randn(n, 3, 32, 32, generator=g)   # the 'micro' preset: 32 px, 5 tokens
         self.y = torch.randint(0, 10, (n,), generator=g)
 
     def __len__(self):
@@ -95,11 +95,11 @@ class _TinyFloatSet(torch.utils.data.Dataset):
 
 
 def test_train_model_checkpoint_and_resume(tmp_path):
-    """two epochs of the finetune loop on the tiny model (simulator backend): tuple checkpoints, resume-from-latest"""
+    """two epochs of the finetune loop on the micro model (simulator backend): tuple checkpoints, resume-from-latest"""
     from touhouimageclassification_amd.ViT.model import ViT
     from touhouimageclassification_amd.optim import FusedAdamW
     torch.manual_seed(0)
-    model = ViT(10, pretrained=False, model_name="tiny", backend=SimBackend())
+    model = ViT(10, pretrained=False, model_name="micro", backend=SimBackend())
     opt = FusedAdamW(model, lr=1e-3, weight_decay=0.01)
     sch = torch.optim.lr_scheduler.StepLR(opt, 1, 0.5)
     save = str(tmp_path / "ViT_model_finetune_{epoch}.pth")
@@ -109,7 +109,7 @@ def test_train_model_checkpoint_and_resume(tmp_path):
     ck = torch.load(save.format(epoch=1), weights_only=False)
     assert isinstance(ck, tuple) and len(ck) == 3 and "vit.layers.0.mlp.fc1.weight" in ck[0]
     # resume: a fresh model picks up epoch 1 and trains epoch 2 only
-    model2 = ViT(10, pretrained=False, model_name="tiny", backend=SimBackend())
+    model2 = ViT(10, pretrained=False, model_name="micro", backend=SimBackend())
     opt2 = FusedAdamW(model2, lr=1e-3, weight_decay=0.01)
     sch2 = torch.optim.lr_scheduler.StepLR(opt2, 1, 0.5)
     tl2 = ft.train_model(model2, _TinyFloatSet(10), opt2, sch2, torch.nn.CrossEntropyLoss(), batch_size=3, num_epochs=2, max_tolerant_epoch=3,

@@ -1,4 +1,4 @@
-"""ResMoE counterpart: dense MoE on tiny ViTs through the simulator backend, and the expert-parallel form on
+"""ResMoE counterpart: dense MoE on micro ViTs through the simulator backend, and the expert-parallel form on
 2 gloo ranks (one expert per rank, all-gather + all-to-all) against the single-process dense model."""
 import os
 import socket
@@ -14,15 +14,15 @@ E, C, B = 2, 5, 2
 def _build(backend):
     from touhouimageclassification_amd.ResMoE.model import make_ViTMoE
     torch.manual_seed(11)
-    m = make_ViTMoE(num_classes=C, num_experts=E, top_k=2, gateway_t=0.01, pretrained=False, model_name="tiny", gate_pretrained=False,
-                    backend=backend, gate_model_name="tiny")
+    m = make_ViTMoE(num_classes=C, num_experts=E, top_k=2, gateway_t=0.01, pretrained=False, model_name="micro", gate_pretrained=False,
+                    backend=backend, gate_model_name="micro")
     m.eval()   # no gate noise: deterministic comparison
     return m
 
 
 def _data():
     g = torch.Generator().manual_seed(5)
-    return torch.randn(E * B, 3, 224, 224, generator=g), torch.randint(0, C, (E * B,), generator=g)
+    return torch.randn(E * B, 3, 32, 32, generator=g), torch.randint(0, C, (E * B,), generator=g)
 
 
 def test_dense_moe_step_and_losses():

@@ -44,7 +44,7 @@ def test_layernorm_strided_cls_rows(env):
     kc.check_layernorm_strided_cls_rows(env)
 
 
-@pytest.mark.parametrize("B,H,N", [(1, 2, 197), (2, 1, 50)])
+@pytest.mark.parametrize("B,H,N", [(1, 2, 197), (2, 1, 50), (3, 2, 5), (1, 1, 33)])
 def test_attention_fwd_bwd(env, B, H, N):
     kc.check_attention_fwd_bwd(env, B, H, N)
 

@@ -31,6 +31,7 @@ _PRESETS = {
     "base": dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072),
     "large": dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096),
     "tiny": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512),
+    "micro": dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128, image_size=32),   # 5 tokens: harness tests
 }
 
 
@@ -221,7 +222,7 @@ def _config_from(model_name: Optional[str], num_classes: int, wrap_model_name: b
                 cfg[k] = j[k]
     else:
         low = (model_name or "").lower()
-        key = "tiny" if "tiny" in low else ("base" if "base" in low else "large")
+        key = "micro" if "micro" in low else ("tiny" if "tiny" in low else ("base" if "base" in low else "large"))
         cfg.update(_PRESETS[key])
     cfg["num_labels"] = num_classes
     cfg["_local_dir"] = local

@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
     const int g = l >> 4, qi = l & 15;
     const float c = p.scale * 1.4426950408889634f;
     const float NEG_INF = -__builtin_huge_valf();
-    for (int qb = w; qb < 13; qb += 4) {
+    const int n16 = (N + 15) >> 4;   // 13 at N = 197; shorter sequences skip the all-padding query blocks
+    for (int qb = w; qb < n16; qb += 4) {
         const int q = qb * 16 + qi;
         // Q fragments (B operand of S^T = K.Q^T): query q, d = 32ks + 8g .. +7, straight from HBM
         bf16x8 fq[2];
@@ -200,6 +201,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
 
     const int g = l >> 4, li = l & 15;
     const float c = p.scale * 1.4426950408889634f;
+    const int n16 = (N + 15) >> 4, n32 = (N + 31) >> 5;   // 13 / 7 at N = 197: tiles / tile pairs that hold real tokens
 
     // ---------------- phase A: dK, dV (key on the lane) -- waves 0..7 ----------------
     f32x4 bk[4], bv[4];   // per-lane bias-gradient partials summed over this wave's tiles: (dk, dv) in phase A, (dq, -) in phase B
@@ -209,7 +211,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
         bv[dt] = f32x4{0, 0, 0, 0};
     }
     if (w < 8)
-    for (int kt = w; kt < 13; kt += 8) {
+    for (int kt = w; kt < n16; kt += 8) {
         const int key = kt * 16 + li;
         const bool key_ok = key < N;
         bf16x8 fk[2], fv[2];
@@ -225,7 +227,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
             dka[dt] = f32x4{0, 0, 0, 0};
         }
 #pragma nounroll
-        for (int qp = 0; qp < 7; ++qp) {
+        for (int qp = 0; qp < n32; ++qp) {
             f32x4 pv[2], dsv[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -272,7 +274,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
 
     // ---------------- phase B: dQ (query on the lane) -- waves 8..15 ----------------
     if (w >= 8)
-    for (int qb = w - 8; qb < 13; qb += 8) {
+    for (int qb = w - 8; qb < n16; qb += 8) {
         const int q = qb * 16 + li;
         bf16x8 fq[2], fd[2];
 #pragma unroll
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dqa[dt] = f32x4{0, 0, 0, 0};
 #pragma nounroll
-        for (int kp = 0; kp < 7; ++kp) {
+        for (int kp = 0; kp < n32; ++kp) {
             f32x4 dsv[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
