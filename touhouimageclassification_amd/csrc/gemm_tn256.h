@@ -47,7 +47,8 @@ TIC_DEV void tn_tile_lookup(const GemmTnGroupParams& gp, int tile, const bf16_t*
 // One 256x256 output tile (origin n0, k0 of problem A/B/C) over the M steps [step0, step1) of 64 rows.
 // ATOMIC = false: the workgroup owns the whole reduction, C += acc with plain read-modify-write;
 // ATOMIC = true : partial reduction (stream-K share), C += acc with fp32 atomics (two 128-B row segments / instruction).
-template <bool ATOMIC>
+// DBG (measurement only, see gemm256.h): bit 0 = no LDS-DMA, bit 1 = no fragment reads, bit 2 = no MFMA.
+template <bool ATOMIC, int DBG = 0>
 TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, int N, int K, int M, int n0, int k0, int step0, int step1) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wr = w >> 2, wc = w & 3;
@@ -71,6 +72,7 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
     const uint32_t stepA = (uint32_t)N * 128u, stepB = (uint32_t)K * 128u;   // 64 rows in bytes
     // which: 0 = A0, 1 = B0, 2 = B1, 3 = A1 ; each call also advances that half-tile's offsets to the next step
     auto issue = [&](int buf, int which) {
+        if (DBG & 1) return;
         const bool isA = (which == 0 || which == 3);
         const int h = (which >= 2) ? 1 : 0;
         const uint32_t base = (uint32_t)buf * G256_BUF_BYTES + (isA ? 0u : 32768u) + (uint32_t)h * 16384u + (uint32_t)(2 * w) * 1024u;
@@ -87,14 +89,21 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
         }
     };
 
-    // ---- transposed fragments (32x32x16): lane (h2 = l>>5, c16 = (l>>4)&1, q = (l>>2)&3, p4 = l&3)
+    // ---- transposed fragments (32x32x16): lane (h2 = l>>5, c16 = (l>>4)&1, q = (l>>2)&3, p4 = l&3).
+    // Fragment address = lane part (VGPR, one per column group) + buffer base + compile-time offset (half-tile, 16 ks rows,
+    // +4 rows for the second read): the reads are hidden from hipcc (lds_tr64_hidden) so that no vmcnt(0) is put in front
+    // of them; they are ordered against the LDS-DMA by the counted vmcnt + barrier schedule below.
     const uint32_t h2 = (uint32_t)l >> 5, c16 = ((uint32_t)l >> 4) & 1u, q4 = ((uint32_t)l >> 2) & 3u, p4 = (uint32_t)l & 3u;
-    auto tr_frag = [&](uint32_t half_base, uint32_t col0, uint32_t ks) -> bf16x8 {
+    auto lane_addr = [&](uint32_t col0) -> uint32_t {
         const uint32_t col = col0 + 16 * c16 + 4 * p4;
-        const uint32_t row = 16 * ks + 8 * h2 + q4;             // row & 3 == q4 for both reads
-        const uint32_t inrow = (((col >> 3) ^ (q4 << 2)) * 16u) + (col & 4u) * 2u;
-        const bf16x4 lo = lds_tr64(half_base + row * 256u + inrow);
-        const bf16x4 hi = lds_tr64(half_base + (row + 4u) * 256u + inrow);
+        const uint32_t row = 8 * h2 + q4;                        // (row + 16 ks) & 3 == q4 for both reads
+        return lds_base() + row * 256u + (((col >> 3) ^ (q4 << 2)) * 16u) + (col & 4u) * 2u;
+    };
+    const uint32_t a_lane[2] = {lane_addr((uint32_t)wr * 64), lane_addr((uint32_t)wr * 64 + 32)};
+    const uint32_t b_lane = lane_addr((uint32_t)wc * 32);
+    auto tr_frag = [&](uint32_t addr, uint32_t imm) -> bf16x8 {
+        const bf16x4 lo = lds_tr64_hidden(addr, imm);
+        const bf16x4 hi = lds_tr64_hidden(addr, imm + 1024u);
         return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
 
@@ -108,18 +117,34 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][nt][r] = 0.f;
     bf16x8 fa[2][4], fb0[4], fb1[4];   // [nt][ks], [ks]; B0 fragments live for the whole step
+    if (DBG & 2) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fa[0][x] = fa[1][x] = fb0[x] = fb1[x] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+    }
 
     auto load_a = [&](uint32_t bufb, int i) {
+        if (DBG & 2) return;
 #pragma unroll
         for (uint32_t nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (uint32_t ks = 0; ks < 4; ++ks) fa[nt][ks] = tr_frag(bufb + (uint32_t)i * 16384u, (uint32_t)wr * 64 + nt * 32, ks);
+            for (uint32_t ks = 0; ks < 4; ++ks) fa[nt][ks] = tr_frag(a_lane[nt] + bufb, (uint32_t)i * 16384u + ks * 4096u);
     };
     auto load_b = [&](uint32_t bufb, int j, bf16x8 (&fb)[4]) {
+        if (DBG & 2) return;
 #pragma unroll
-        for (uint32_t ks = 0; ks < 4; ++ks) fb[ks] = tr_frag(bufb + 32768u + (uint32_t)j * 16384u, (uint32_t)wc * 32, ks);
+        for (uint32_t ks = 0; ks < 4; ++ks) fb[ks] = tr_frag(b_lane + bufb, 32768u + (uint32_t)j * 16384u + ks * 4096u);
+    };
+    auto wait_a = [&]() {
+        if (!(DBG & 2)) lds_wait(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[1][0], fa[1][1], fa[1][2], fa[1][3]);
+    };
+    auto wait_b = [&](bf16x8 (&fb)[4]) {
+        if (!(DBG & 2)) lds_wait(fb[0], fb[1], fb[2], fb[3]);
     };
     auto mma = [&](int i, int j, const bf16x8 (&fb)[4]) {
+        if (DBG & 4) {
+            acc[i][j][0][0] += (float)fa[0][0][0] + (float)fa[1][3][1] + (float)fb[0][0] + (float)fb[3][1];   // keep the reads alive
+            return;
+        }
         prio_hi();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
@@ -149,17 +174,21 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
         issue(cur ^ 1, 2);   // B1(st+1)
         wait_vmcnt<8>();
         g256_barrier();
+        wait_a();
+        wait_b(fb0);
         mma(0, 0, fb0);
         g256_barrier();
         load_b(bufb, 1, fb1);
         issue(cur ^ 1, 3);   // A1(st+1)
         wait_vmcnt<8>();
         g256_barrier();
+        wait_b(fb1);
         mma(0, 1, fb1);
         g256_barrier();
         load_a(bufb, 1);
         issue(cur, 0);       // A0(st+2)
         g256_barrier();
+        wait_a();
         mma(1, 1, fb1);
         g256_barrier();
         issue(cur, 1);       // B0(st+2)
@@ -189,6 +218,7 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
             }
 }
 
+template <int DBG = 0>
 __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp) {
     // XCD-contiguous tile order, then problem lookup (wave-uniform)
     int wg;
@@ -201,7 +231,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
     float* Cp;
     int N, K, n0, k0;
     tn_tile_lookup(gp, wg, Ap, Bp, Cp, N, K, n0, k0);
-    tn256_tile_segment<false>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, (gp.M + 63) / 64);
+    tn256_tile_segment<false, DBG>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, (gp.M + 63) / 64);
 }
 
 // Stream-K forms: every CU gets an equal share of the (tile, M step) work instead of 192 busy + 64 idle CUs.  A share is

@@ -222,8 +222,21 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
             TIC_LAUNCH(gemm_tn256_streamk_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
             return tic_after_launch("gemm_tn_group(stream-K)");
         }
-        TIC_RT_MAX_LDS(gemm_tn256_kernel, G256_LDS_BYTES);
-        TIC_LAUNCH(gemm_tn256_kernel, t, 512, G256_LDS_BYTES, stream, gp);
+        if (g_opt_gemm_dbg) {
+#define TIC_DBG_CASE(D)                                                                   \
+    case D:                                                                               \
+        TIC_RT_MAX_LDS(gemm_tn256_kernel<D>, G256_LDS_BYTES);                             \
+        TIC_LAUNCH(gemm_tn256_kernel<D>, t, 512, G256_LDS_BYTES, stream, gp);             \
+        break;
+            switch (g_opt_gemm_dbg) {
+                TIC_DBG_CASE(1) TIC_DBG_CASE(2) TIC_DBG_CASE(3) TIC_DBG_CASE(4) TIC_DBG_CASE(5) TIC_DBG_CASE(6) TIC_DBG_CASE(7)
+                default: return tic_fail(TIC_EINVAL, "gemm_tn_group: gemm_dbg %d has no TN variant", g_opt_gemm_dbg);
+            }
+#undef TIC_DBG_CASE
+            return tic_after_launch("gemm_tn_group(dbg)");
+        }
+        TIC_RT_MAX_LDS(gemm_tn256_kernel<0>, G256_LDS_BYTES);
+        TIC_LAUNCH(gemm_tn256_kernel<0>, t, 512, G256_LDS_BYTES, stream, gp);
         return tic_after_launch("gemm_tn_group");
     }
     for (int g = 0; g < nprob; ++g) TIC_TRY(tic_gemm_tn_bf16(A[g], B[g], C[g], M, N[g], K[g], stream));

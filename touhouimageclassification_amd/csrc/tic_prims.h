@@ -51,6 +51,24 @@ TIC_DEV bf16x4 lds_tr64(uint32_t off) {
             (__attribute__((address_space(3))) char*)tic_smem + off));
 }
 
+// The same read hidden from hipcc (inline asm): beside LDS-DMA in flight the compiler orders every LDS read it KNOWS of
+// behind `s_waitcnt vmcnt(0)` (it sees buffer_load..lds as an LDS write that may alias), which drains the whole
+// prefetch pipeline in every phase.  `addr` = LDS byte address in a VGPR (lds_base() + offset), `imm` = compile-time
+// offset < 65536.  The caller waits with lds_wait(...) naming every destination before the first consumer (guide
+// section 5.7 item 1, form (ii)) and orders the reads against the DMA by its own counted vmcnt + barrier.
+TIC_DEV uint32_t lds_base() { return (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)tic_smem); }
+TIC_DEV bf16x4 lds_tr64_hidden(uint32_t addr, uint32_t imm) {
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(imm));
+    return r;
+}
+TIC_DEV void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+TIC_DEV void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+
 // ---- buffer resources + LDS-DMA -----------------------------------------------------------------
 typedef __amdgpu_buffer_rsrc_t tic_rsrc_t;
 // bytes: hardware range check -- loads past it return 0, stores past it are dropped.
