@@ -116,86 +116,151 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][nt][r] = 0.f;
-    bf16x8 fa[2][4], fb0[4], fb1[4];   // [nt][ks], [ks]; B0 fragments live for the whole step
+    // fragment registers: A0 / A1 of the current step ([nt][ks], 16 m rows per ks) and two B sets whose roles (B0 | B1)
+    // swap every step.  Same schedule as gemm256.h (see the hazard table there): a load segment only issues one
+    // half-tile and waits vmcnt(8); the fragment reads ride under the MFMAs of the previous phase, A in two ks halves so
+    // that the fragment peak is 80 VGPRs.
+    bf16x8 fa0[2][4], fa1[2][4], fbx[4], fby[4];
     if (DBG & 2) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) fa[0][x] = fa[1][x] = fb0[x] = fb1[x] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
+        for (int x = 0; x < 4; ++x) fa0[0][x] = fa0[1][x] = fa1[0][x] = fa1[1][x] = fbx[x] = fby[x] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8};
     }
-
-    auto load_a = [&](uint32_t bufb, int i) {
+    auto rd_a = [&](uint32_t bufb, int i, bf16x8 (&fa)[2][4], uint32_t ks) {   // 4 reads
         if (DBG & 2) return;
 #pragma unroll
-        for (uint32_t nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (uint32_t ks = 0; ks < 4; ++ks) fa[nt][ks] = tr_frag(a_lane[nt] + bufb, (uint32_t)i * 16384u + ks * 4096u);
+        for (uint32_t nt = 0; nt < 2; ++nt) fa[nt][ks] = tr_frag(a_lane[nt] + bufb, (uint32_t)i * 16384u + ks * 4096u);
     };
-    auto load_b = [&](uint32_t bufb, int j, bf16x8 (&fb)[4]) {
+    auto rd_b = [&](uint32_t bufb, int j, bf16x8 (&fb)[4], uint32_t ks) {      // 2 reads
         if (DBG & 2) return;
-#pragma unroll
-        for (uint32_t ks = 0; ks < 4; ++ks) fb[ks] = tr_frag(b_lane + bufb, 32768u + (uint32_t)j * 16384u + ks * 4096u);
+        fb[ks] = tr_frag(b_lane + bufb, 32768u + (uint32_t)j * 16384u + ks * 4096u);
     };
-    auto wait_a = [&]() {
-        if (!(DBG & 2)) lds_wait(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[1][0], fa[1][1], fa[1][2], fa[1][3]);
-    };
-    auto wait_b = [&](bf16x8 (&fb)[4]) {
-        if (!(DBG & 2)) lds_wait(fb[0], fb[1], fb[2], fb[3]);
-    };
-    auto mma = [&](int i, int j, const bf16x8 (&fb)[4]) {
+    auto mma = [&](int i, int j, const bf16x8 (&fa)[2][4], const bf16x8 (&fb)[4], int ks) {   // 2 MFMAs
         if (DBG & 4) {
-            acc[i][j][0][0] += (float)fa[0][0][0] + (float)fa[1][3][1] + (float)fb[0][0] + (float)fb[3][1];   // keep the reads alive
+            acc[i][j][0][0] += (float)fa[0][ks][0] + (float)fa[1][ks][1] + (float)fb[ks][0];   // keep the reads alive
             return;
         }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[i][j][nt] = mfma32(fa[nt][ks], fb[ks], acc[i][j][nt]);
+    };
+    // one 64-row step; on entry B0(t) is in fbp and ks 0,1 of A0(t) in fa0; on exit the same for t+1 with fbq.
+    // sched_fence() pins the hand interleave (the reads are inline asm: hipcc neither counts nor places them).
+    auto step = [&](int st, bf16x8 (&fbp)[4], bf16x8 (&fbq)[4]) {
+        const int cur = st & 1;
+        const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES, bufn = (uint32_t)(cur ^ 1) * G256_BUF_BYTES;
+        // ---- phase 0: Q00 = A0 x B0 ; reads A0(t) ks 2,3 and B1(t)
+        issue(cur ^ 1, 3);   // A1(t+1)
+        wait_vmcnt<8>();
+        g256_barrier();
         prio_hi();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[i][j][nt] = mfma32(fa[nt][ks], fb[ks], acc[i][j][nt]);
+        rd_a(bufb, 0, fa0, 2);
+        rd_a(bufb, 0, fa0, 3);
+        sched_fence();
+        mma(0, 0, fa0, fbp, 0);
+        sched_fence();
+        rd_b(bufb, 1, fbq, 0);
+        rd_b(bufb, 1, fbq, 1);
+        sched_fence();
+        mma(0, 0, fa0, fbp, 1);
+        sched_fence();
+        rd_b(bufb, 1, fbq, 2);
+        rd_b(bufb, 1, fbq, 3);
+        if (!(DBG & 2)) lds_wait<8>(fa0[0][2], fa0[0][3], fa0[1][2], fa0[1][3]);   // the 8 B1 reads may still be out
+        sched_fence();
+        mma(0, 0, fa0, fbp, 2);
+        mma(0, 0, fa0, fbp, 3);
+        sched_fence();
+        if (!(DBG & 2)) lds_wait<0>(fbq[0], fbq[1], fbq[2], fbq[3]);
         prio_lo();
+        g256_barrier();
+        // ---- phase 1: Q01 = A0 x B1 ; reads A1(t) ks 0,1
+        issue(cur, 1);       // B0(t+2)
+        wait_vmcnt<8>();
+        g256_barrier();
+        prio_hi();
+        mma(0, 1, fa0, fbq, 0);
+        sched_fence();
+        rd_a(bufb, 1, fa1, 0);
+        sched_fence();
+        mma(0, 1, fa0, fbq, 1);
+        sched_fence();
+        rd_a(bufb, 1, fa1, 1);
+        sched_fence();
+        mma(0, 1, fa0, fbq, 2);
+        mma(0, 1, fa0, fbq, 3);
+        sched_fence();
+        if (!(DBG & 2)) lds_wait<0>(fa1[0][0], fa1[0][1], fa1[1][0], fa1[1][1]);
+        prio_lo();
+        g256_barrier();
+        // ---- phase 2: Q11 = A1 x B1 ; reads A1(t) ks 2,3
+        issue(cur, 0);       // A0(t+2)
+        wait_vmcnt<8>();
+        g256_barrier();
+        prio_hi();
+        rd_a(bufb, 1, fa1, 2);
+        rd_a(bufb, 1, fa1, 3);
+        sched_fence();
+        mma(1, 1, fa1, fbq, 0);
+        mma(1, 1, fa1, fbq, 1);
+        sched_fence();
+        if (!(DBG & 2)) lds_wait<0>(fa1[0][2], fa1[0][3], fa1[1][2], fa1[1][3]);
+        sched_fence();
+        mma(1, 1, fa1, fbq, 2);
+        mma(1, 1, fa1, fbq, 3);
+        prio_lo();
+        g256_barrier();
+        // ---- phase 3: Q10 = A1 x B0 ; reads A0(t+1) ks 0,1 and B0(t+1)
+        issue(cur, 2);       // B1(t+2)
+        wait_vmcnt<8>();
+        g256_barrier();
+        prio_hi();
+        mma(1, 0, fa1, fbp, 0);
+        sched_fence();
+        rd_a(bufn, 0, fa0, 0);
+        sched_fence();
+        mma(1, 0, fa1, fbp, 1);
+        sched_fence();
+        rd_a(bufn, 0, fa0, 1);
+        sched_fence();
+        mma(1, 0, fa1, fbp, 2);
+        sched_fence();
+        rd_b(bufn, 0, fbq, 0);
+        rd_b(bufn, 0, fbq, 1);
+        sched_fence();
+        mma(1, 0, fa1, fbp, 3);
+        sched_fence();
+        rd_b(bufn, 0, fbq, 2);
+        rd_b(bufn, 0, fbq, 3);
+        if (!(DBG & 2)) lds_wait<0>(fa0[0][0], fa0[0][1], fa0[1][0], fa0[1][1], fbq[0], fbq[1], fbq[2], fbq[3]);
+        prio_lo();
+        g256_barrier();
     };
 
-    // same 5-6-phase-deep schedule as gemm256.h; steps past the end read rows >= M, i.e. zero fills
-    const int nsteps = step1 - step0;
-    issue(0, 0);
+    // prologue: all of step 0 and B0, A0, B1 of step 1 in the steady-state issue order B0, A0, B1, A1; steps past the end of
+    // the segment read rows >= row_end, i.e. zero fills; B0(0), A0(0), B1(0) landed; first fragments; group 1 falls behind
     issue(0, 1);
+    issue(0, 0);
     issue(0, 2);
     issue(0, 3);
-    issue(1, 0);
     issue(1, 1);
+    issue(1, 0);
+    issue(1, 2);
     wait_vmcnt<8>();
     g256_barrier();
+    rd_a(0u, 0, fa0, 0);
+    rd_a(0u, 0, fa0, 1);
+    rd_b(0u, 0, fbx, 0);
+    rd_b(0u, 0, fbx, 1);
+    rd_b(0u, 0, fbx, 2);
+    rd_b(0u, 0, fbx, 3);
+    if (!(DBG & 2)) lds_wait<0>(fa0[0][0], fa0[0][1], fa0[1][0], fa0[1][1], fbx[0], fbx[1], fbx[2], fbx[3]);
     if (wr == 1) g256_barrier();
 
+    // two steps per trip (the B register sets swap roles); an odd count runs one extra all-zero step (rows >= row_end)
+    const int nsteps = step1 - step0;
 #pragma nounroll
-    for (int st = 0; st < nsteps; ++st) {
-        const int cur = st & 1;
-        const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES;
-        load_a(bufb, 0);
-        load_b(bufb, 0, fb0);
-        issue(cur ^ 1, 2);   // B1(st+1)
-        wait_vmcnt<8>();
-        g256_barrier();
-        wait_a();
-        wait_b(fb0);
-        mma(0, 0, fb0);
-        g256_barrier();
-        load_b(bufb, 1, fb1);
-        issue(cur ^ 1, 3);   // A1(st+1)
-        wait_vmcnt<8>();
-        g256_barrier();
-        wait_b(fb1);
-        mma(0, 1, fb1);
-        g256_barrier();
-        load_a(bufb, 1);
-        issue(cur, 0);       // A0(st+2)
-        g256_barrier();
-        wait_a();
-        mma(1, 1, fb1);
-        g256_barrier();
-        issue(cur, 1);       // B0(st+2)
-        wait_vmcnt<8>();
-        g256_barrier();
-        mma(1, 0, fb0);
-        g256_barrier();
+    for (int st = 0; st < nsteps; st += 2) {
+        step(st, fbx, fby);
+        step(st + 1, fby, fbx);
     }
     wait_vmcnt0();
     if (wr == 0) g256_barrier();

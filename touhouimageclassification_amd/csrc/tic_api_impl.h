@@ -190,7 +190,7 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
     for (int g = 0; g < nprob; ++g) {
         TIC_REQUIRE(A[g] && B[g] && C[g] && TIC_ALIGNED16(A[g]) && TIC_ALIGNED16(B[g]), "gemm_tn_group: null / misaligned operand %d", g);
         TIC_REQUIRE(N[g] % 8 == 0 && K[g] % 8 == 0 && N[g] >= 8 && K[g] >= 8, "gemm_tn_group: need N, K multiples of 8 (problem %d: N=%d K=%d)", g, N[g], K[g]);
-        TIC_REQUIRE(((double)M + 64.0) * (N[g] > K[g] ? N[g] : K[g]) * 2.0 < 4294967296.0, "gemm_tn_group: operand exceeds the 4 GiB buffer-resource range");
+        TIC_REQUIRE(((double)M + 320.0) * (N[g] > K[g] ? N[g] : K[g]) * 2.0 < 4294967296.0, "gemm_tn_group: operand exceeds the 4 GiB buffer-resource range");
         if (N[g] % 256 || K[g] % 256) ok256 = false;
         tiles += (N[g] / 256) * (K[g] / 256);
     }

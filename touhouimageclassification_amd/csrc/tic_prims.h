@@ -62,11 +62,14 @@ TIC_DEV bf16x4 lds_tr64_hidden(uint32_t addr, uint32_t imm) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(imm));
     return r;
 }
+// N = LDS operations that may still be outstanding (they return in order): lds_wait<8>(...) after 8 + 8 reads has the first 8 landed
+template <int N = 0>
 TIC_DEV void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
+template <int N = 0>
 TIC_DEV void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e, bf16x8& f, bf16x8& g, bf16x8& h) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N));
 }
 
 // ---- buffer resources + LDS-DMA -----------------------------------------------------------------
