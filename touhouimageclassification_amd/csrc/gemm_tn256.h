@@ -177,13 +177,14 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
         wait_vmcnt<8>();
         g256_barrier();
         prio_hi();
+        mma(0, 1, fa0, fbq, 0);
+        sched_fence();
         rd_a(bufb, 1, fa1, 0);
         sched_fence();
-        mma(0, 1, fa0, fbq, 0);
+        mma(0, 1, fa0, fbq, 1);
         sched_fence();
         rd_a(bufb, 1, fa1, 1);
         sched_fence();
-        mma(0, 1, fa0, fbq, 1);
         mma(0, 1, fa0, fbq, 2);
         mma(0, 1, fa0, fbq, 3);
         sched_fence();
@@ -212,22 +213,23 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
         wait_vmcnt<8>();
         g256_barrier();
         prio_hi();
+        mma(1, 0, fa1, fbp, 0);
+        sched_fence();
         rd_a(bufn, 0, fa0, 0);
+        sched_fence();
+        mma(1, 0, fa1, fbp, 1);
+        sched_fence();
         rd_a(bufn, 0, fa0, 1);
         sched_fence();
-        mma(1, 0, fa1, fbp, 0);
+        mma(1, 0, fa1, fbp, 2);
         sched_fence();
         rd_b(bufn, 0, fbq, 0);
         rd_b(bufn, 0, fbq, 1);
         sched_fence();
-        mma(1, 0, fa1, fbp, 1);
+        mma(1, 0, fa1, fbp, 3);
         sched_fence();
         rd_b(bufn, 0, fbq, 2);
         rd_b(bufn, 0, fbq, 3);
-        sched_fence();
-        mma(1, 0, fa1, fbp, 2);
-        mma(1, 0, fa1, fbp, 3);
-        sched_fence();
         if (!(DBG & 2)) lds_wait<0>(fa0[0][0], fa0[0][1], fa0[1][0], fa0[1][1], fbq[0], fbq[1], fbq[2], fbq[3]);
         prio_lo();
         g256_barrier();
