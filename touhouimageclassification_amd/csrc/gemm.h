@@ -327,6 +327,12 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
         return tile_base + row * 256u + chunk * 16u + (col & 4u) * 2u;
     };
 
+    uint32_t tr_lane[2][2];   // [operand][t]: lane part of the fragment address (ks and the +4-row read are immediates)
+#pragma unroll
+    for (uint32_t t = 0; t < 2; ++t) {
+        tr_lane[0][t] = lds_base() + tr_off(0u, (uint32_t)wn * 64 + t * 32, 0, 0);
+        tr_lane[1][t] = lds_base() + tr_off(0u, (uint32_t)wk * 64 + t * 32, 0, 0);
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -342,22 +348,33 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
         const int cur = st & 1;
         if (st + 1 < nsteps) stage(cur ^ 1);
         const uint32_t sb = (uint32_t)cur * GEMM_STAGE_BYTES;
-#pragma unroll
-        for (uint32_t ks = 0; ks < 4; ++ks) {
-            bf16x8 fa[2], fb[2];
+        // fragment reads hidden from hipcc (it would put vmcnt(0) in front of them and serialise the prefetch of the
+        // next stage with this stage's MFMAs); ks+1 is read while ks is multiplied
+        bf16x8 fa[2][2], fb[2][2];   // [ks & 1][t]
+        auto rd = [&](uint32_t ks) {
 #pragma unroll
             for (uint32_t t = 0; t < 2; ++t) {
-                const bf16x4 a0 = lds_tr64(tr_off(sb, (uint32_t)wn * 64 + t * 32, ks, 0));
-                const bf16x4 a1 = lds_tr64(tr_off(sb, (uint32_t)wn * 64 + t * 32, ks, 1));
-                const bf16x4 b0 = lds_tr64(tr_off(sb + 16384u, (uint32_t)wk * 64 + t * 32, ks, 0));
-                const bf16x4 b1 = lds_tr64(tr_off(sb + 16384u, (uint32_t)wk * 64 + t * 32, ks, 1));
-                fa[t] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                fb[t] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                const bf16x4 a0 = lds_tr64_hidden(tr_lane[0][t] + sb, ks * 4096u);
+                const bf16x4 a1 = lds_tr64_hidden(tr_lane[0][t] + sb, ks * 4096u + 1024u);
+                const bf16x4 b0 = lds_tr64_hidden(tr_lane[1][t] + sb, 16384u + ks * 4096u);
+                const bf16x4 b1 = lds_tr64_hidden(tr_lane[1][t] + sb, 16384u + ks * 4096u + 1024u);
+                fa[ks & 1][t] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                fb[ks & 1][t] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            }
+        };
+        rd(0);
+#pragma unroll
+        for (uint32_t ks = 0; ks < 4; ++ks) {
+            if (ks < 3) {
+                rd(ks + 1);
+                lds_wait<8>(fa[ks & 1][0], fa[ks & 1][1], fb[ks & 1][0], fb[ks & 1][1]);   // the 8 reads of ks+1 may still be out
+            } else {
+                lds_wait<0>(fa[ks & 1][0], fa[ks & 1][1], fb[ks & 1][0], fb[ks & 1][1]);
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt) acc[nt][kt] = mfma32(fa[nt], fb[kt], acc[nt][kt]);
+                for (int kt = 0; kt < 2; ++kt) acc[nt][kt] = mfma32(fa[ks & 1][nt], fb[ks & 1][kt], acc[nt][kt]);
         }
         wait_vmcnt0();
         block_sync();
