@@ -31,7 +31,13 @@ typedef void* tic_stream_t; /* hipStream_t */
 #define TIC_ABI_VERSION 1
 int tic_version(void);
 const char* tic_last_error_string(void);
-/* process-wide tuning knobs for A/B measurements: "gemm_tile" = 0 (auto) | 128 | 256 ; "tn_streamk" = 1 | 0 */
+/* process-wide knobs for A/B measurements (never needed for correct results):
+ *   "gemm_tile"  0 (auto) | 128 | 256       which NT / TN tile family to use
+ *   "tn_streamk" 1 (256 shares) | 0 | n     stream-K split of the grouped dW launch
+ *   "tn_phase"   1 | 0                      phase-aligned vs flat stream-K split
+ *   "gemm_dbg"   0..15                      measurement builds of the 256x256 kernels with parts of the main loop compiled
+ *                                           out (bit 0 no LDS-DMA, 1 no fragment reads, 2 no MFMA, 3 deeper queue): GARBAGE
+ *                                           results by construction, tools/gemm_dbg.py only */
 int tic_set_option(const char* name, int value);
 
 /* GEMM epilogues (fused into the MFMA kernel's store) */
