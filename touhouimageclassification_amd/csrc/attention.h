@@ -161,9 +161,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
 // LDS: Q | K | V | dO tiles, then lse[224] and delta[224] floats
 #define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4 + 3 * ATT_HD * 4)   // + per-block q/k/v bias-gradient sums
 
-// 16 waves, no barrier between the phases (both only read the LDS tiles and write disjoint outputs): wave w runs key
-// tile w of phase A (dK, dV), then query block 15 - w of phase B (dQ).  With 13 tiles per phase every wave has at most
-// one tile of each (critical path 1 A + 1 B instead of 2 A), and each SIMD hosts 3-4 tiles of each phase at any time.
+// 16 waves: waves 0-7 run phase A (dK, dV), waves 8-15 run phase B (dQ) CONCURRENTLY -- both only read the LDS tiles and
+// write disjoint outputs, so every SIMD hosts two waves of each phase and their latencies overlap (the 13 key tiles /
+// 13 query blocks of a head are dealt to 8 waves each: critical path 2 tiles instead of 4).
 __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     const int l = lane_id(), w = wave_id(), tid = TIC_TID;
     const int bh = TIC_BID_X, b = bh / p.H, h = bh - b * p.H;
@@ -177,27 +177,23 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     att_stage_tile<16>(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
     att_stage_tile<16>(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
     att_stage_tile<16>(rdo, DOT, row0, N, D, h * ATT_HD, l, w);
-    // delta[q] = sum_d dO[q,d] * O[q,d] (4 threads per row, 16 columns each);  lse (log2 units); padded queries: lse = +inf -> P = 0
-    {
-        const int row = tid >> 2, part = tid & 3;   // 1024 threads cover 256 >= ATT_ROWS rows
-        float dl = 0.f;
-        if (row < N) {
-            const bf16_t* orow = p.o + (size_t)(row0 + row) * D + h * ATT_HD + part * 16;
-            const bf16_t* drow = p.d_o + (size_t)(row0 + row) * D + h * ATT_HD + part * 16;
+    // delta[q] = sum_d dO[q,d] * O[q,d];  lse (log2 units); padded queries: lse = +inf -> P = 0
+    if (tid < ATT_ROWS) {
+        float dl = 0.f, ls = __builtin_huge_valf();
+        if (tid < N) {
+            const bf16_t* orow = p.o + (size_t)(row0 + tid) * D + h * ATT_HD;
+            const bf16_t* drow = p.d_o + (size_t)(row0 + tid) * D + h * ATT_HD;
 #pragma unroll
-            for (int c8 = 0; c8 < 2; ++c8) {
+            for (int c8 = 0; c8 < 8; ++c8) {
                 const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + c8 * 8);
                 const bf16x8 dv = *reinterpret_cast<const bf16x8*>(drow + c8 * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)ov[j]) * bf2f((bf16_t)dv[j]);
             }
+            ls = p.lse[(size_t)bh * N + tid] * 1.4426950408889634f;
         }
-        dl += shfl_xor(dl, 1);
-        dl += shfl_xor(dl, 2);
-        if (part == 0 && row < ATT_ROWS) {
-            lds_stf(LSE + 4u * row, row < N ? p.lse[(size_t)bh * N + row] * 1.4426950408889634f : __builtin_huge_valf());
-            lds_stf(DEL + 4u * row, dl);
-        }
+        lds_stf(LSE + 4u * tid, ls);
+        lds_stf(DEL + 4u * tid, dl);
     }
     if (tid < 3 * ATT_HD) lds_stf(DBL + 4u * tid, 0.f);
     wait_vmcnt0();
@@ -214,7 +210,8 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
         bk[dt] = f32x4{0, 0, 0, 0};
         bv[dt] = f32x4{0, 0, 0, 0};
     }
-    for (int kt = w; kt < n16; kt += 16) {
+    if (w < 8)
+    for (int kt = w; kt < n16; kt += 8) {
         const int key = kt * 16 + li;
         const bool key_ok = key < N;
         bf16x8 fk[2], fv[2];
@@ -275,29 +272,9 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
         }
     }
 
-    // q/k/v bias gradient: lanes (16 rows) -> wave (butterfly) -> workgroup (LDS adds) -> ONE global atomic per column.
-    // Adding per tile straight to global memory put thousands of workgroups on the same 3D addresses (14x slower atomics).
-    auto reduce_cols = [&](const f32x4 (&part)[4], uint32_t lds_col0) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = part[dt][r];
-#pragma unroll
-                for (int msk = 1; msk < 16; msk <<= 1) a += shfl_xor(a, msk);
-                if (li == 0) lds_addf(DBL + 4u * (lds_col0 + (uint32_t)(dt * 16 + 4 * g + r)), a);
-            }
-    };
-    if (p.dbias) {   // kernel argument: uniform
-        reduce_cols(bk, 64u);
-        reduce_cols(bv, 128u);
-    }
-    f32x4 bq[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) bq[dt] = f32x4{0, 0, 0, 0};
-
     // ---------------- phase B: dQ (query on the lane) -- waves 8..15 ----------------
-    for (int qb = 15 - w; qb < n16; qb += 16) {
+    if (w >= 8)
+    for (int qb = w - 8; qb < n16; qb += 8) {
         const int q = qb * 16 + li;
         bf16x8 fq[2], fd[2];
 #pragma unroll
@@ -334,7 +311,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
             for (int dt = 0; dt < 4; ++dt) dqa[dt] = mfma16(att_tr_frag(KT, kp, dt, l), fds, dqa[dt]);   // dQ^T[d][q]
         }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) bq[dt] += dqa[dt];
+        for (int dt = 0; dt < 4; ++dt) bk[dt] += dqa[dt];
         if (q < N) {
             bf16_t* qrow = p.dqkv + (size_t)(row0 + q) * ld + h * ATT_HD + 4 * g;
 #pragma unroll
@@ -342,8 +319,29 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                 *reinterpret_cast<u32x2*>(qrow + dt * 16) = u32x2{pack2bf(dqa[dt][0], dqa[dt][1]), pack2bf(dqa[dt][2], dqa[dt][3])};
         }
     }
+    // q/k/v bias gradient: lanes (16 rows) -> wave (butterfly) -> workgroup (LDS adds) -> ONE global atomic per column.
+    // Adding per tile straight to global memory put 2 656 workgroups on the same 3D addresses (14x slower atomics).
     if (p.dbias) {   // kernel argument: uniform
-        reduce_cols(bq, 0u);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = bk[dt][r], b2 = bv[dt][r];
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) {
+                    a += shfl_xor(a, msk);
+                    b2 += shfl_xor(b2, msk);
+                }
+                if (li == 0) {
+                    const uint32_t col = (uint32_t)(dt * 16 + 4 * g + r);
+                    if (w < 8) {
+                        lds_addf(DBL + 4u * (64u + col), a);
+                        lds_addf(DBL + 4u * (128u + col), b2);
+                    } else {
+                        lds_addf(DBL + 4u * col, a);
+                    }
+                }
+            }
         block_sync();
         if (tid < 3 * ATT_HD) atomic_addf(p.dbias + (tid >> 6) * D + h * ATT_HD + (tid & 63), lds_ldf(DBL + 4u * tid));
     }
