@@ -177,23 +177,27 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     att_stage_tile<16>(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
     att_stage_tile<16>(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
     att_stage_tile<16>(rdo, DOT, row0, N, D, h * ATT_HD, l, w);
-    // delta[q] = sum_d dO[q,d] * O[q,d];  lse (log2 units); padded queries: lse = +inf -> P = 0
-    if (tid < ATT_ROWS) {
-        float dl = 0.f, ls = __builtin_huge_valf();
-        if (tid < N) {
-            const bf16_t* orow = p.o + (size_t)(row0 + tid) * D + h * ATT_HD;
-            const bf16_t* drow = p.d_o + (size_t)(row0 + tid) * D + h * ATT_HD;
+    // delta[q] = sum_d dO[q,d] * O[q,d] (4 threads per row, 16 columns each);  lse (log2 units); padded queries: lse = +inf -> P = 0
+    {
+        const int row = tid >> 2, part = tid & 3;   // 1024 threads cover 256 >= ATT_ROWS rows
+        float dl = 0.f;
+        if (row < N) {
+            const bf16_t* orow = p.o + (size_t)(row0 + row) * D + h * ATT_HD + part * 16;
+            const bf16_t* drow = p.d_o + (size_t)(row0 + row) * D + h * ATT_HD + part * 16;
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
+            for (int c8 = 0; c8 < 2; ++c8) {
                 const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + c8 * 8);
                 const bf16x8 dv = *reinterpret_cast<const bf16x8*>(drow + c8 * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)ov[j]) * bf2f((bf16_t)dv[j]);
             }
-            ls = p.lse[(size_t)bh * N + tid] * 1.4426950408889634f;
         }
-        lds_stf(LSE + 4u * tid, ls);
-        lds_stf(DEL + 4u * tid, dl);
+        dl += shfl_xor(dl, 1);
+        dl += shfl_xor(dl, 2);
+        if (part == 0 && row < ATT_ROWS) {
+            lds_stf(LSE + 4u * row, row < N ? p.lse[(size_t)bh * N + row] * 1.4426950408889634f : __builtin_huge_valf());
+            lds_stf(DEL + 4u * row, dl);
+        }
     }
     if (tid < 3 * ATT_HD) lds_stf(DBL + 4u * tid, 0.f);
     wait_vmcnt0();
