@@ -30,6 +30,7 @@ struct GemmNtParams {
     const float* rowtab;     // [(P+1),N] fp32 (PATCH: position embeddings)
     int patches;             // P (PATCH)
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the consumer), BF16 / DGELU
+    int stagger;             // experiment (tic_set_option "gemm_stagger"): s_sleep rounds for every other first-wave workgroup
 };
 
 // 16-byte-chunk XOR swizzle for 128-byte LDS rows: conflict-free for the 16x16x32 row-fragment

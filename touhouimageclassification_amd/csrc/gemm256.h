@@ -214,6 +214,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     int tm, tn;
     tile_coords(TIC_BID_X, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
+#ifndef TIC_SIM
+    // experiment: delay every other workgroup of the first wave of tiles so that epilogues (HBM bursts) of one half of the
+    // CUs fall into the main loops of the other half
+    if (p.stagger > 0 && TIC_BID_X < 256 && ((TIC_BID_X >> 3) & 1))
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     const tic_rsrc_t ra = make_rsrc(p.A, (uint32_t)((size_t)p.M * p.K * 2));
     const tic_rsrc_t rb = make_rsrc(p.B, (uint32_t)((size_t)p.N * p.K * 2));
 

@@ -45,10 +45,15 @@ static int tic_after_launch(const char* what) {
 // tuning knobs (process-wide, for A/B measurements and tests): "gemm_tile" = 0 (auto) | 128 | 256 ;
 // "tn_streamk" = 1 (default: grouped dW as 256 equal stream-K shares) | 0 (one workgroup per full-M tile)
 static int g_opt_gemm_tile = 0;
-static int g_opt_gemm_dbg = 0;    // measurement only: see gemm256.h DBG
+static int g_opt_gemm_dbg = 0;
+static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 extern "C" int tic_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "gemm_stagger") && value >= -1 && value <= 64) {
+        g_opt_gemm_stagger = value;
+        return TIC_OK;
+    }
     if (name && !strcmp(name, "gemm_dbg") && value >= 0 && value < 16) {
         g_opt_gemm_dbg = value;
         return TIC_OK;
@@ -96,11 +101,16 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     memset(&p, 0, sizeof(p));
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K;
     p.bias = (epilogue == TIC_EPI_DGELU || epilogue == TIC_EPI_MULAUX) ? nullptr : bias;
+
     p.out = (bf16_t*)out_bf16; p.out2 = (bf16_t*)out2_bf16; p.out_f32 = out_f32; p.resid = resid;
     p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches; p.colsum = colsum;
     // big products go to the deep-pipelined 256x256 kernel (one block per CU), the rest to the 128x128 one
     const bool big = (N % 256 == 0) && (g_opt_gemm_tile == 256 || (g_opt_gemm_tile == 0 && (long)M * N >= (long)2048 * 1024));
     const int grid = big ? (int)(((M + 255) / 256) * (N / 256)) : (int)(tiles_m * ((N + 127) / 128));
+    // every other first-wave workgroup starts ~8 us late when the epilogue is the VALU-heavy GELU one and a CU runs >= 4
+    // tiles: the two halves of the chip then alternate between epilogue and main loop (tools/stagger_probe.py: 694 -> 618 us
+    // for fc1 at M = 65 404; no gain for the other epilogues)
+    p.stagger = g_opt_gemm_stagger >= 0 ? g_opt_gemm_stagger : ((epilogue == TIC_EPI_GELU_DG && grid >= 4 * 256) ? 2 : 0);
 #define TIC_GEMM_NT_LAUNCH(E)                                                                        \
     do {                                                                                             \
         if (big) {                                                                                   \
