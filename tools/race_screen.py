@@ -37,6 +37,44 @@ for (M, N, K) in ((1576, 2304, 768), (1576, 3072, 768), (3136, 1024, 768), (3270
 call("tic_set_option", b"gemm_tile", 0)
 print("gemm race screen:", "CLEAN" if bad == 0 else f"{bad} mismatching outputs", flush=True)
 
+# dW (TN) kernels: the one-tile-per-workgroup form has no atomics -> repeated launches must agree bit for bit; the
+# stream-K forms add partial tiles with fp32 atomics -> equal to the plain result up to fp32 summation order
+import ctypes
+bad_tn = 0
+for (M, shapes) in ((32702, [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 1024)]), (16351, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),
+                    (4099, [(256, 512), (512, 256)]), (65, [(256, 256)])):
+    As = [torch.randn(M, n, device=dev).to(torch.bfloat16) for n, k in shapes]
+    Bs = [torch.randn(M, k, device=dev).to(torch.bfloat16) for n, k in shapes]
+    G = len(shapes)
+    PA = (ctypes.c_void_p * G)(*[t.data_ptr() for t in As]); PB = (ctypes.c_void_p * G)(*[t.data_ptr() for t in Bs])
+    NN = (ctypes.c_int * G)(*[s_[0] for s_ in shapes]); KK = (ctypes.c_int * G)(*[s_[1] for s_ in shapes])
+    def run(streamk, phase):
+        call("tic_set_option", b"gemm_tile", 256); call("tic_set_option", b"tn_streamk", streamk); call("tic_set_option", b"tn_phase", phase)
+        Cs = [torch.zeros(n, k, device=dev) for n, k in shapes]
+        PC = (ctypes.c_void_p * G)(*[t.data_ptr() for t in Cs])
+        call("tic_gemm_tn_group_bf16", G, PA, PB, PC, NN, KK, M, current_stream())
+        torch.cuda.synchronize()
+        return Cs
+    plain = [run(0, 1) for _ in range(5)]
+    for i in range(1, 5):
+        for a, b in zip(plain[i], plain[0]):
+            if not torch.equal(a, b):
+                print(f"TN MISMATCH plain kernel M={M} rep {i}: {int((a != b).sum())} elements differ", flush=True); bad_tn += 1
+    ref = [A.float().t() @ B.float() for A, B in zip(As, Bs)]
+    for a, r in zip(plain[0], ref):
+        err = float((a - r).abs().max() / r.abs().max())
+        if err > 2e-5:
+            print(f"TN plain kernel vs fp32 matmul M={M}: rel err {err:.3e}", flush=True); bad_tn += 1
+    for sk, ph in ((1, 1), (1, 0), (7, 0)):
+        for rep in range(3):
+            out = run(sk, ph)
+            for a, b in zip(out, plain[0]):
+                err = float((a - b).abs().max() / b.abs().max())
+                if err > 2e-5:
+                    print(f"TN MISMATCH stream-K({sk},{ph}) M={M} rep {rep}: rel err {err:.3e}", flush=True); bad_tn += 1
+call("tic_set_option", b"gemm_tile", 0); call("tic_set_option", b"tn_streamk", 1); call("tic_set_option", b"tn_phase", 1)
+print("dW race screen:", "CLEAN" if bad_tn == 0 else f"{bad_tn} problems", flush=True)
+
 from touhouimageclassification_amd.ViT.model import ViT
 from touhouimageclassification_amd.optim import FusedAdamW
 from touhouimageclassification_amd.step import fused_train_step

@@ -107,10 +107,11 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     // big products go to the deep-pipelined 256x256 kernel (one block per CU), the rest to the 128x128 one
     const bool big = (N % 256 == 0) && (g_opt_gemm_tile == 256 || (g_opt_gemm_tile == 0 && (long)M * N >= (long)2048 * 1024));
     const int grid = big ? (int)(((M + 255) / 256) * (N / 256)) : (int)(tiles_m * ((N + 127) / 128));
-    // every other first-wave workgroup starts ~8 us late when the epilogue is the VALU-heavy GELU one and a CU runs >= 4
-    // tiles: the two halves of the chip then alternate between epilogue and main loop (tools/stagger_probe.py: 694 -> 618 us
-    // for fc1 at M = 65 404; no gain for the other epilogues)
-    p.stagger = g_opt_gemm_stagger >= 0 ? g_opt_gemm_stagger : ((epilogue == TIC_EPI_GELU_DG && grid >= 4 * 256) ? 2 : 0);
+    // experiment knob (off by default): every other first-wave workgroup starts n x ~4 us late so that the two halves of the
+    // chip alternate between epilogue and main loop.  Stand-alone back-to-back launches of fc1+GELU gain 11 %
+    // (tools/stagger_probe.py); inside the training step the gain is zero (tools/ab_step.py gemm_stagger 0 2: 141.8 vs
+    // 141.9 ms) -- there the previous kernel's tail already starts the CUs at different times.
+    p.stagger = g_opt_gemm_stagger > 0 ? g_opt_gemm_stagger : 0;
 #define TIC_GEMM_NT_LAUNCH(E)                                                                        \
     do {                                                                                             \
         if (big) {                                                                                   \
