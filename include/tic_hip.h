@@ -144,8 +144,18 @@ int tic_mix_labels(const int64_t* y, float* out, int B, int ncls, float lam, tic
 /* ---- ResNet conv path (TIC/ResNet/model.py; activations NHWC bf16, weights master fp32 OIHW) --------------
  * A convolution is a GEMM over the kernels above: Y[M,Co] = col(X)[M,Kp] . Wp[Co,Kp]^T with M = B*Ho*Wo and
  * Kp = kh*kw*Ci rounded up to 64 (tap-major k = (ky*kw+kx)*Ci + c); 1x1 stride-1 convs use X itself as col(X). */
-/* transposed != 0 writes [Kp, Co] (the B operand of the dgrad GEMM) */
-int tic_conv_weight_pack(const float* w_oihw, void* w16_ohwi, int Co, int Ci, int kh, int kw, int transposed, tic_stream_t stream); /* model.py:8-9,14,148 */
+/* transposed = 1 writes [Kp, Co] (the B operand of the explicit dgrad GEMM); transposed = 2 writes the implicit-GEMM dgrad
+ * filter [Ci][(ky',kx')*Co + o] = w[o][c][kh-1-ky'][kw-1-kx']                                   model.py:8-9,14,148 */
+int tic_conv_weight_pack(const float* w_oihw, void* w16_ohwi, int Co, int Ci, int kh, int kw, int transposed, tic_stream_t stream);
+/* Implicit-GEMM convolution (no im2col buffer) for filters with Cin % 64 == 0 -- the 3x3 convolutions of TIC/ResNet/model.py:6-9
+ * (Bottleneck conv2 :87, BasicBlock conv1/conv2 :31-36).  x is NHWC bf16, w_pack = tic_conv_weight_pack(..., transposed = 0).
+ *   fwd   : y[B*Ho*Wo, Cout] (bf16) = conv(x, w)            -- also the stride-1 input gradient: call it with dY as x, Cin/Cout
+ *           swapped, pad = k-1-pad and w_pack = tic_conv_weight_pack(..., transposed = 2) (flipped, channel-transposed filter)
+ *   wgrad : dw[Cout, kh*kw*Cin] (fp32, tap-major, += with atomics) = dY^T . gather(x); fold into OIHW with tic_conv_weight_grad */
+int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                       int stride, int pad, tic_stream_t stream);
+int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* dw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                         int stride, int pad, tic_stream_t stream);
 int tic_conv_weight_grad(const float* dw_ohwi, float* grad_oihw, int Co, int Ci, int kh, int kw, tic_stream_t stream); /* grad += */
 int tic_nchw_to_nhwc_bf16(const float* x, void* out_bf16, int B, int C, int H, int W, tic_stream_t stream);
 int tic_im2col_bf16(const void* x, void* col, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, tic_stream_t stream);

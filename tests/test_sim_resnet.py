@@ -97,3 +97,9 @@ def test_batchnorm_and_pools_against_torch():
 def test_resnet18_step_matches_reference_golden(golden_dir):
     worst = rc.check_against_golden("resnet18", golden_dir, SimBackend(), torch.device("cpu"), logit_tol=5e-2, gnorm_tol=0.12)
     print("worst grad-norm rel err", worst)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(2, 9, 7, 64, 64, 1), (1, 12, 12, 128, 72, 2), (3, 6, 6, 64, 192, 1)])
+def test_implicit_gemm_conv3x3(B, H, W, Cin, Cout, stride):
+    """tic_conv_igemm_fwd / _wgrad (and the stride-1 dgrad through the flipped filter) against F.conv2d on CPU tensors"""
+    rc.check_implicit_conv(lambda name, *a: call(name, *a), torch.device("cpu"), B, H, W, Cin, Cout, stride)

@@ -123,8 +123,9 @@ class TicResNet(nn.Module):
         self._call("tic_gemm_nt_bf16", A.data_ptr(), Bw.data_ptr(), M, N, K, 0, None, out.data_ptr(), None, None, None, None, None, 0)
         return out
 
-    def _pack(self, conv: _Conv, transposed: bool):
-        """bf16 GEMM operand of a conv weight ([Cout, Kp] or its transpose), re-packed only when the fp32 weight changed"""
+    def _pack(self, conv: _Conv, transposed):
+        """bf16 GEMM operand of a conv weight ([Cout, Kp], its transpose (1), or the flipped channel-transposed filter of the
+        implicit-GEMM input gradient (2)), re-packed only when the fp32 weight changed"""
         w = conv.weight
         key = (w._version, w.data_ptr(), w.device)
         cache = conv.__dict__.setdefault("_packed", {})
@@ -133,22 +134,32 @@ class TicResNet(nn.Module):
             cache["key"] = key
         if transposed not in cache:
             kp = conv.kp
-            out = torch.empty((kp, conv.cout) if transposed else (conv.cout, kp), dtype=torch.bfloat16, device=w.device)
-            self._call("tic_conv_weight_pack", w.data_ptr(), out.data_ptr(), conv.cout, conv.cin, conv.k, conv.k, 1 if transposed else 0)
+            shape = {0: (conv.cout, kp), 1: (kp, conv.cout), 2: (conv.cin, conv.k * conv.k * conv.cout)}[int(transposed)]
+            out = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
+            self._call("tic_conv_weight_pack", w.data_ptr(), out.data_ptr(), conv.cout, conv.cin, conv.k, conv.k, int(transposed))
             cache[transposed] = out
         return cache[transposed]
+
+    @staticmethod
+    def _implicit(conv: _Conv) -> bool:
+        return conv.k > 1 and conv.cin % 64 == 0 and conv.cout % 8 == 0
 
     def _conv_fwd(self, conv: _Conv, x, B, H, W):
         """x [B,H,W,Cin] bf16 -> (y [M,Cout] bf16, col or None, Ho, Wo)"""
         Ho = (H + 2 * conv.pad - conv.k) // conv.stride + 1
         Wo = (W + 2 * conv.pad - conv.k) // conv.stride + 1
         M = B * Ho * Wo
+        if self._implicit(conv):   # 3x3: gather inside the GEMM, no im2col buffer (the backward gathers again from x)
+            y = torch.empty(M, conv.cout, dtype=torch.bfloat16, device=x.device)
+            self._call("tic_conv_igemm_fwd", x.data_ptr(), self._pack(conv, 0).data_ptr(), y.data_ptr(), B, H, W, conv.cin, conv.cout,
+                       conv.k, conv.k, conv.stride, conv.pad)
+            return y, x, Ho, Wo
         if conv.k == 1 and conv.stride == 1:
             col = x
         else:
             col = torch.empty(M, conv.kp, dtype=torch.bfloat16, device=x.device)
             self._call("tic_im2col_bf16", x.data_ptr(), col.data_ptr(), B, H, W, conv.cin, conv.k, conv.k, conv.stride, conv.pad)
-        return self._gemm_nt(col, self._pack(conv, False), M, conv.cout, conv.kp), col, Ho, Wo
+        return self._gemm_nt(col, self._pack(conv, 0), M, conv.cout, conv.kp), col, Ho, Wo
 
     def _bn_fwd(self, bn: _BN, x, M, identity, relu, train):
         dev = x.device
@@ -195,11 +206,23 @@ class TicResNet(nn.Module):
         """dy [M,Cout]; returns dx [B*H*W, Cin] bf16 (or None) and accumulates the weight gradient"""
         M = dy.shape[0]
         dw = conv.__dict__["_dw_view"]   # zeroed by _begin_backward
-        self._call("tic_gemm_tn_bf16", dy.data_ptr(), col.data_ptr(), dw.data_ptr(), M, conv.cout, conv.kp)
+        if self._implicit(conv):   # col is the NHWC input itself
+            self._call("tic_conv_igemm_wgrad", dy.data_ptr(), col.data_ptr(), dw.data_ptr(), B, H, W, conv.cin, conv.cout, conv.k, conv.k,
+                       conv.stride, conv.pad)
+        else:
+            self._call("tic_gemm_tn_bf16", dy.data_ptr(), col.data_ptr(), dw.data_ptr(), M, conv.cout, conv.kp)
         self._call("tic_conv_weight_grad", dw.data_ptr(), self._grad_buf(conv.weight).data_ptr(), conv.cout, conv.cin, conv.k, conv.k)
         if not need_dx:
             return None
-        dcol = self._gemm_nt(dy, self._pack(conv, True), M, conv.kp, conv.cout)
+        if self._implicit(conv) and conv.stride == 1 and conv.cout % 64 == 0 and dx_accumulate_into is None:
+            # input gradient = the same gather GEMM over dY with the flipped, channel-transposed filter
+            Ho = (H + 2 * conv.pad - conv.k) // conv.stride + 1
+            Wo = (W + 2 * conv.pad - conv.k) // conv.stride + 1
+            dx = torch.empty(B * H * W, conv.cin, dtype=torch.bfloat16, device=dy.device)
+            self._call("tic_conv_igemm_fwd", dy.data_ptr(), self._pack(conv, 2).data_ptr(), dx.data_ptr(), B, Ho, Wo, conv.cout, conv.cin,
+                       conv.k, conv.k, 1, conv.k - 1 - conv.pad)
+            return dx
+        dcol = self._gemm_nt(dy, self._pack(conv, 1), M, conv.kp, conv.cout)
         if conv.k == 1 and conv.stride == 1:
             if dx_accumulate_into is not None:
                 self._call("tic_add_bf16", dx_accumulate_into.data_ptr(), dcol.data_ptr(), dcol.numel())

@@ -16,8 +16,20 @@ struct ConvGeom {
     int B, H, W, Ci, Ho, Wo, kh, kw, stride, pad, K, Kp;   // K = kh*kw*Ci, Kp = K rounded up to 64
 };
 
-// OIHW fp32 -> [Co, Kp] bf16 with k = (ky*kw + kx)*Ci + c, zero padded; transposed != 0 writes [Kp, Co] (dgrad operand)
+// OIHW fp32 -> [Co, Kp] bf16 with k = (ky*kw + kx)*Ci + c, zero padded; transposed == 1 writes [Kp, Co] (operand of the
+// explicit dgrad GEMM); transposed == 2 writes the implicit-GEMM dgrad filter [Ci][(ky', kx') * Co + o] = w[o][c][kh-1-ky'][kw-1-kx']
 __global__ void __launch_bounds__(256) weight_ohwi_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Co, ConvGeom g, int transposed) {
+    if (transposed == 2) {
+        const long total2 = (long)g.Ci * g.kh * g.kw * Co;
+        for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total2; i += (long)TIC_NBLK_X * 256) {
+            const int o = (int)(i % Co);
+            long t = i / Co;
+            const int tap = (int)(t % (g.kh * g.kw)), c = (int)(t / (g.kh * g.kw));
+            const int ky = g.kh - 1 - tap / g.kw, kx = g.kw - 1 - tap % g.kw;
+            out[i] = f2bf(w[(((long)o * g.Ci + c) * g.kh + ky) * g.kw + kx]);
+        }
+        return;
+    }
     const long total = (long)Co * g.Kp;
     for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
         const int o = (int)(i / g.Kp), k = (int)(i - (long)o * g.Kp);

@@ -17,8 +17,16 @@
 // epilogue codes: TIC_EPI_* in include/tic_hip.h
 #include "../../include/tic_hip.h"
 
+// Implicit-GEMM convolution: the A operand is never materialised -- row m = output pixel (n, oy, ox) and K tile kt
+// (64 channels of ONE filter tap, Cin % 64 == 0) is gathered straight from the NHWC activation:
+//   A[m][k = (ky*KW + kx)*Cin + c] = x[n][oy*stride - pad + ky][ox*stride - pad + kx][c]   (0 outside the image)
+// Replaces F.conv2d forward for 3x3 convolutions (TIC/ResNet/model.py:6-9) and, fed with dY and the flipped/transposed
+// filter, its stride-1 input gradient.
+struct ConvGather {
+    int H, W, Cin, Ho, Wo, KW, stride, pad;
+};
 struct GemmNtParams {
-    const bf16_t* A;   // [M,K]
+    const bf16_t* A;   // [M,K]  (CONV: the NHWC activation [B,H,W,Cin])
     const bf16_t* B;   // [N,K]
     int M, N, K;
     const float* bias;       // [N] or nullptr
@@ -30,6 +38,7 @@ struct GemmNtParams {
     const float* rowtab;     // [(P+1),N] fp32 (PATCH: position embeddings)
     int patches;             // P (PATCH)
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the consumer), BF16 / DGELU
+    ConvGather cg;           // gemm_nt_kernel<EPI, true> only
     int stagger;             // experiment (tic_set_option "gemm_stagger"): s_sleep rounds for every other first-wave workgroup
 };
 
@@ -169,7 +178,7 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
 #define GEMM_STAGE_BYTES 32768   // A tile 16 KiB + B tile 16 KiB
 #define GEMM_LDS_BYTES (2 * GEMM_STAGE_BYTES)
 
-template <int EPI>
+template <int EPI, bool CONV = false>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wm = w >> 1, wn = w & 1;
@@ -178,24 +187,47 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
     tile_coords(TIC_BID_X, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
 
-    const tic_rsrc_t ra = make_rsrc(p.A, (uint32_t)((size_t)p.M * p.K * 2));
+    const size_t a_bytes = CONV ? (size_t)(p.M / (p.cg.Ho * p.cg.Wo)) * p.cg.H * p.cg.W * p.cg.Cin * 2 : (size_t)p.M * p.K * 2;
+    const tic_rsrc_t ra = make_rsrc(p.A, (uint32_t)a_bytes);
     const tic_rsrc_t rb = make_rsrc(p.B, (uint32_t)((size_t)p.N * p.K * 2));
 
     // ---- LDS-DMA source offsets (bytes) for this lane's 4 A chunks and 4 B chunks --------------
     // chunk c = i*4 + w covers tile rows 8c..8c+7 (1 KiB); lane -> (row l>>3, physical 16-B slot l&7)
     uint32_t voa[4], vob[4];
+    int iy0[4], ix0[4];   // CONV: top-left input coordinate of this row's window (row >= M: far outside the image)
     {
         const uint32_t slot_log = (uint32_t)(l & 7) ^ ((((uint32_t)l >> 4) & 3u) << 1);   // = phys ^ swz128(row)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = (i * 4 + w) * 8 + (l >> 3);
-            voa[i] = (uint32_t)(((size_t)(m0 + r) * p.K + slot_log * 8) * 2);
+            if (CONV) {
+                const int m = m0 + r, hw = p.cg.Ho * p.cg.Wo;
+                const int n = m / hw, rem = m - n * hw, oy = rem / p.cg.Wo, ox = rem - oy * p.cg.Wo;
+                iy0[i] = (m < p.M) ? oy * p.cg.stride - p.cg.pad : -(1 << 20);
+                ix0[i] = ox * p.cg.stride - p.cg.pad;
+                // 32-bit wrap is fine: the tap offset added in stage() brings every in-image address back into range
+                voa[i] = (uint32_t)((((long)n * p.cg.H + iy0[i]) * p.cg.W + ix0[i]) * p.cg.Cin * 2 + (long)slot_log * 16);
+            } else {
+                voa[i] = (uint32_t)(((size_t)(m0 + r) * p.K + slot_log * 8) * 2);
+            }
             vob[i] = (uint32_t)(((size_t)(n0 + r) * p.K + slot_log * 8) * 2);
         }
     }
     auto stage = [&](int buf, int kt) {
         const uint32_t soff = (uint32_t)kt * (GEMM_BK * 2);
         const uint32_t base = (uint32_t)buf * GEMM_STAGE_BYTES;
+        if (CONV) {
+            const int kk = kt * GEMM_BK, tap = kk / p.cg.Cin, c0 = kk - tap * p.cg.Cin;   // wave-uniform
+            const int ky = tap / p.cg.KW, kx = tap - ky * p.cg.KW;
+            const uint32_t tapoff = (uint32_t)(((ky * p.cg.W + kx) * p.cg.Cin + c0) * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool in = (unsigned)(iy0[i] + ky) < (unsigned)p.cg.H && (unsigned)(ix0[i] + kx) < (unsigned)p.cg.W;
+                glds16(ra, base + (uint32_t)(i * 4 + w) * 1024u, in ? voa[i] + tapoff : 0xFFFFFFF0u, 0);
+                glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, vob[i], soff);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             glds16(ra, base + (uint32_t)(i * 4 + w) * 1024u, voa[i], soff);
@@ -263,15 +295,24 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
 //   LDS tiles: [64 m][128 n or k] bf16 = 256-B rows, 16 KiB each.
 struct GemmTnParams {
     const bf16_t* A;   // [M,N]
-    const bf16_t* B;   // [M,K]
+    const bf16_t* B;   // [M,K]  (CONV: the NHWC activation [B,H,W,Cin]; B[m][k] gathered as in ConvGather)
     float* C;          // [N,K]
     int M, N, K;
     int m_per_slice;   // multiple of 64
+    ConvGather cg;     // gemm_tn_kernel<true> only
 };
+// floor(m / d) for 0 <= m < 2^24 from a float reciprocal (the hardware has no integer divide; this is 5 VALU ops)
+TIC_DEV int div_small(int m, int d, float inv) {
+    int q = (int)((float)m * inv);
+    if (q * d > m) --q;
+    if ((q + 1) * d <= m) ++q;
+    return q;
+}
 
 // 16-B-chunk swizzle for 256-byte rows read by the 32x32x16 transposed-fragment pattern
 TIC_DEV uint32_t swz256(uint32_t row) { return (row & 3u) << 2; }
 
+template <bool CONV = false>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wn = w >> 1, wk = w & 1;
@@ -287,7 +328,8 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
 
     // range check at the END OF THIS SLICE so a partial last step reads zeros, not the next slice
     const tic_rsrc_t ra = make_rsrc(p.A, (uint32_t)((size_t)m_end * p.N * 2));
-    const tic_rsrc_t rb = make_rsrc(p.B, (uint32_t)((size_t)m_end * p.K * 2));
+    const size_t b_bytes = CONV ? (size_t)(p.M / (p.cg.Ho * p.cg.Wo)) * p.cg.H * p.cg.W * p.cg.Cin * 2 : (size_t)m_end * p.K * 2;
+    const tic_rsrc_t rb = make_rsrc(p.B, (uint32_t)b_bytes);
 
     // staging: a 1-KiB DMA piece = 4 rows x 256 B; piece c = i*4 + w covers tile rows 4c..4c+3;
     // lane -> (row l>>4, physical chunk l&15); source chunk = phys ^ swz256(row)
@@ -305,6 +347,22 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
             vob[i] = (uint32_t)(((size_t)(m_begin + r) * p.K + k0 + ch_log * 8) * 2);
         }
     }
+    // CONV: this lane's 8 columns of the B tile belong to ONE filter tap (Cin % 64 == 0): (ky, kx, channel offset) are fixed,
+    // the pixel of row m changes every step
+    int c_ky = 0, c_kx = 0, c_row = 0, c_m = 0;
+    uint32_t c_choff = 0;
+    float inv_hw = 0.f, inv_w = 0.f;
+    if (CONV) {
+        const uint32_t rr = (uint32_t)l >> 4, ch_log = ((uint32_t)l & 15u) ^ (rr << 2);
+        const int kcol = k0 + (int)ch_log * 8, tap = kcol / p.cg.Cin;
+        c_ky = tap / p.cg.KW;
+        c_kx = tap - c_ky * p.cg.KW;
+        c_choff = (uint32_t)((kcol - tap * p.cg.Cin) * 2);
+        c_row = w * 4 + (int)rr;     // piece i adds 16 rows
+        c_m = m_begin;
+        inv_hw = 1.0f / (float)(p.cg.Ho * p.cg.Wo);
+        inv_w = 1.0f / (float)p.cg.Wo;
+    }
     // the row advance lives in the VGPR offset: only that offset is range-checked by the hardware
     const uint32_t strideA = (uint32_t)p.N * 2 * 64, strideB = (uint32_t)p.K * 2 * 64;   // bytes per 64-row step
     auto stage = [&](int buf) {
@@ -312,10 +370,20 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             glds16(ra, base + (uint32_t)(i * 4 + w) * 1024u, a_ok ? voa[i] : 0xFFFFFFF0u, 0);
-            glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, b_ok ? vob[i] : 0xFFFFFFF0u, 0);
+            if (CONV) {
+                const int m = c_m + c_row + i * 16, hw = p.cg.Ho * p.cg.Wo;
+                const int n = div_small(m, hw, inv_hw), rem = m - n * hw, oy = div_small(rem, p.cg.Wo, inv_w), ox = rem - oy * p.cg.Wo;
+                const int iy = oy * p.cg.stride - p.cg.pad + c_ky, ix = ox * p.cg.stride - p.cg.pad + c_kx;
+                const bool in = b_ok && m < m_end && (unsigned)iy < (unsigned)p.cg.H && (unsigned)ix < (unsigned)p.cg.W;
+                const uint32_t off = (uint32_t)((((long)n * p.cg.H + iy) * p.cg.W + ix) * p.cg.Cin * 2) + c_choff;
+                glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, in ? off : 0xFFFFFFF0u, 0);
+            } else {
+                glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, b_ok ? vob[i] : 0xFFFFFFF0u, 0);
+                vob[i] += strideB;
+            }
             voa[i] += strideA;
-            vob[i] += strideB;
         }
+        if (CONV) c_m += 64;
     };
 
     // transposed-fragment addresses (32x32x16): lane l: h = l>>5, c16 = (l>>4)&1, q = (l>>2)&3, p4 = l&3

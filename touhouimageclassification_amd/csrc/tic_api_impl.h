@@ -186,8 +186,8 @@ extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, i
     split = (M + m_per - 1) / m_per;
     GemmTnParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.M = M; p.N = N; p.K = K; p.m_per_slice = m_per;
-    TIC_RT_MAX_LDS(gemm_tn_kernel, GEMM_LDS_BYTES);
-    TIC_LAUNCH(gemm_tn_kernel, dim3(tiles, split), 256, GEMM_LDS_BYTES, stream, p);
+    TIC_RT_MAX_LDS(gemm_tn_kernel<false>, GEMM_LDS_BYTES);
+    TIC_LAUNCH(gemm_tn_kernel<false>, dim3(tiles, split), 256, GEMM_LDS_BYTES, stream, p);
     return tic_after_launch("gemm_tn");
 }
 
@@ -444,11 +444,58 @@ static int conv_geom(ConvGeom& g, int B, int H, int W, int Ci, int kh, int kw, i
     return TIC_OK;
 }
 extern "C" int tic_conv_weight_pack(const float* w_oihw, void* w16, int Co, int Ci, int kh, int kw, int transposed, tic_stream_t stream) {
-    TIC_REQUIRE(w_oihw && w16 && Co >= 1, "conv_weight_pack: bad argument");
+    TIC_REQUIRE(w_oihw && w16 && Co >= 1 && transposed >= 0 && transposed <= 2, "conv_weight_pack: bad argument");
     ConvGeom g;
     TIC_TRY(conv_geom(g, 1, kh, kw, Ci, kh, kw, 1, 0));
     TIC_LAUNCH(weight_ohwi_kernel, ew_grid((long)Co * g.Kp), 256, 0, stream, w_oihw, (bf16_t*)w16, Co, g, transposed);
     return tic_after_launch("conv_weight_pack");
+}
+// implicit-GEMM convolution (3x3 and friends with Cin % 64 == 0): y[M = B*Ho*Wo, Cout] = gather(x) . Wpack^T
+extern "C" int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                                  int stride, int pad, tic_stream_t stream) {
+    TIC_REQUIRE(x_nhwc && w_pack && y && B >= 1, "conv_igemm_fwd: bad argument");
+    TIC_REQUIRE(Cin % 64 == 0 && Cout % 8 == 0 && kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "conv_igemm_fwd: need Cin %% 64 == 0, Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    TIC_REQUIRE(Ho >= 1 && Wo >= 1, "conv_igemm_fwd: empty output");
+    const long M = (long)B * Ho * Wo;
+    const int K = kh * kw * Cin;
+    TIC_REQUIRE(M < (1L << 24) && (double)B * H * W * Cin * 2.0 < 4294967296.0 && (double)Cout * K * 2.0 < 4294967296.0,
+                "conv_igemm_fwd: tensor exceeds the 32-bit offset / 2^24 row range");
+    GemmNtParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const bf16_t*)x_nhwc; p.B = (const bf16_t*)w_pack; p.M = (int)M; p.N = Cout; p.K = K; p.out = (bf16_t*)y;
+    p.cg.H = H; p.cg.W = W; p.cg.Cin = Cin; p.cg.Ho = Ho; p.cg.Wo = Wo; p.cg.KW = kw; p.cg.stride = stride; p.cg.pad = pad;
+    const int grid = (int)(((M + 127) / 128) * ((Cout + 127) / 128));
+    TIC_RT_MAX_LDS((gemm_nt_kernel<TIC_EPI_BF16, true>), GEMM_LDS_BYTES);
+    TIC_LAUNCH((gemm_nt_kernel<TIC_EPI_BF16, true>), grid, 256, GEMM_LDS_BYTES, stream, p);
+    return tic_after_launch("conv_igemm_fwd");
+}
+// dW[Cout, kh*kw*Cin] (fp32, tap-major) += dY[M, Cout]^T . gather(x)   -- the weight gradient without an im2col buffer
+extern "C" int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* dw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                                    int stride, int pad, tic_stream_t stream) {
+    TIC_REQUIRE(dy && x_nhwc && dw && B >= 1, "conv_igemm_wgrad: bad argument");
+    TIC_REQUIRE(Cin % 64 == 0 && Cout % 8 == 0 && kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "conv_igemm_wgrad: need Cin %% 64 == 0, Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    TIC_REQUIRE(Ho >= 1 && Wo >= 1, "conv_igemm_wgrad: empty output");
+    const long Ml = (long)B * Ho * Wo;
+    const int K = kh * kw * Cin, N = Cout;
+    TIC_REQUIRE(Ml < (1L << 24) - 64 && (double)B * H * W * Cin * 2.0 < 4294967296.0 && ((double)Ml + 64.0) * Cout * 2.0 < 4294967296.0,
+                "conv_igemm_wgrad: tensor exceeds the 32-bit offset / 2^24 row range");
+    const int M = (int)Ml;
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    int split = (1024 + tiles - 1) / tiles;
+    const int max_split = (M + 63) / 64;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    int m_per = ((M + split - 1) / split + 63) / 64 * 64;
+    split = (M + m_per - 1) / m_per;
+    GemmTnParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const bf16_t*)dy; p.B = (const bf16_t*)x_nhwc; p.C = dw; p.M = M; p.N = N; p.K = K; p.m_per_slice = m_per;
+    p.cg.H = H; p.cg.W = W; p.cg.Cin = Cin; p.cg.Ho = Ho; p.cg.Wo = Wo; p.cg.KW = kw; p.cg.stride = stride; p.cg.pad = pad;
+    TIC_RT_MAX_LDS(gemm_tn_kernel<true>, GEMM_LDS_BYTES);
+    TIC_LAUNCH(gemm_tn_kernel<true>, dim3(tiles, split), 256, GEMM_LDS_BYTES, stream, p);
+    return tic_after_launch("conv_igemm_wgrad");
 }
 extern "C" int tic_conv_weight_grad(const float* dw, float* grad_oihw, int Co, int Ci, int kh, int kw, tic_stream_t stream) {
     TIC_REQUIRE(dw && grad_oihw && Co >= 1, "conv_weight_grad: bad argument");
