@@ -142,7 +142,8 @@ class TicResNet(nn.Module):
 
     @staticmethod
     def _implicit(conv: _Conv) -> bool:
-        return conv.k > 1 and conv.cin % 64 == 0 and conv.cout % 8 == 0
+        # 3x3 convolutions and the strided 1x1 downsample projections (a 1x1 stride-1 conv is a plain GEMM on the activation)
+        return (conv.k > 1 or conv.stride > 1) and conv.cin % 64 == 0 and conv.cout % 8 == 0
 
     def _conv_fwd(self, conv: _Conv, x, B, H, W):
         """x [B,H,W,Cin] bf16 -> (y [M,Cout] bf16, col or None, Ho, Wo)"""
