@@ -38,7 +38,6 @@ struct GemmNtParams {
     const float* rowtab;     // [(P+1),N] fp32 (PATCH: position embeddings)
     int patches;             // P (PATCH)
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the consumer), BF16 / DGELU
-    float* colsumsq;         // optional [N] (EPI_BF16): += column sums of the SQUARED stored output -- with colsum, the BatchNorm batch statistics of a conv output
     ConvGather cg;           // gemm_nt_kernel<EPI, true> only
     int stagger;             // experiment (tic_set_option "gemm_stagger"): s_sleep rounds for every other first-wave workgroup
 };
@@ -88,12 +87,8 @@ TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, EpiExtra e
     if (m >= p.M || n >= p.N) return f32x4{0.f, 0.f, 0.f, 0.f};   // ragged M; N not a multiple of the tile (conv channels 64, C*k*k ...)
     const size_t o = (size_t)m * p.N + n;
     if (EPI == TIC_EPI_BF16) {
-        const u32x2 u = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *reinterpret_cast<u32x2*>(p.out + o) = u;
-        // the STORED (bf16) values: column sums of them are what a consumer of the tensor would compute
-        union { uint32_t i; float f; } a, b, c, d;
-        a.i = u[0] << 16; b.i = u[0] & 0xffff0000u; c.i = u[1] << 16; d.i = u[1] & 0xffff0000u;
-        return f32x4{a.f, b.f, c.f, d.f};
+        *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        return v;
     } else if (EPI == TIC_EPI_GELU) {
         float u[4], g[4];
 #pragma unroll
@@ -140,10 +135,9 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
     constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX || EPI == TIC_EPI_PATCH);
     constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
     EpiExtra ex[2][NG];
-    f32x4 cs[NG], cq[NG];
+    f32x4 cs[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) cs[g] = cq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool want_sq = (EPI == TIC_EPI_BF16) && p.colsumsq;   // kernel-argument condition: wave-uniform
+    for (int g = 0; g < NG; ++g) cs[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (HAS_EXTRA) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) ex[0][g] = epi_fetch<EPI>(p, row_of(0), col_of(g));
@@ -158,7 +152,6 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
         for (int g = 0; g < NG; ++g) {
             const f32x4 w4 = epi_store<EPI>(p, row_of(r), col_of(g), acc_of(r, g), ex[r & 1][g]);
             if (HAS_COLSUM) cs[g] += w4;
-            if (want_sq) cq[g] += w4 * w4;
         }
     }
     // fused bias gradient: this lane's rows are summed above; the 16 lanes that share (l>>4) hold the other rows of the
@@ -174,20 +167,6 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
                 v += shfl_xor(v, 4);
                 v += shfl_xor(v, 8);
                 if ((lane_id() & 15) == 0 && col_of(g) + c < p.N) atomic_addf(p.colsum + col_of(g) + c, v);
-            }
-        }
-    }
-    if (want_sq) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float v = cq[g][c];
-                v += shfl_xor(v, 1);
-                v += shfl_xor(v, 2);
-                v += shfl_xor(v, 4);
-                v += shfl_xor(v, 8);
-                if ((lane_id() & 15) == 0 && col_of(g) + c < p.N) atomic_addf(p.colsumsq + col_of(g) + c, v);
             }
         }
     }
