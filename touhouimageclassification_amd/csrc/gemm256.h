@@ -79,9 +79,7 @@ template <int EPI>
 TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
     constexpr bool HAS_AUX = (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
     constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
-    // all 16 operand rows of a thread are requested at once (the accumulators are dead: 64 registers are free for them):
-    // 128 KiB in flight per CU -- with 4 rows ahead the pass ran at bytes-in-flight / latency = ~32 GB/s per CU
-    constexpr int PF = 16;
+    constexpr int PF = 4;
     const int tid = TIC_TID, c16 = tid & 31, rsub = tid >> 5;
     const int n = n0 + c16 * 8;
     const uint32_t lds0 = (uint32_t)rsub * 512u + (uint32_t)(((c16 * 2) ^ (rsub << 2)) * 8);
@@ -168,7 +166,7 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
 // 4 columns per thread: the fp32-output epilogues (RESID, PATCH).  c8 = tid & 63, rows (tid >> 6) + 8 k.
 template <int EPI>
 TIC_DEV void g256_finish_f32(const GemmNtParams& p, int m0, int n0) {
-    constexpr int PF = 16;   // 16 of the thread's 32 rows in flight (64 registers), the next 16 issued behind them
+    constexpr int PF = 4;
     const int tid = TIC_TID, c8 = tid & 63, rsub = tid >> 6;
     const int n = n0 + c8 * 4;
     f32x4 ex[2][PF];
