@@ -236,11 +236,6 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int qrow = (2 * qp + hh) * 16;
-                if (hh == 1 && qrow >= N) {   // wave-uniform: 16 all-padding queries (rows 208..223 at N = 197) -> P = dS = 0
-                    pv[1] = f32x4{0, 0, 0, 0};
-                    dsv[1] = f32x4{0, 0, 0, 0};
-                    continue;
-                }
                 f32x4 sa = f32x4{0, 0, 0, 0}, da = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -301,10 +296,6 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int krow = (2 * kp + hh) * 16;
-                if (hh == 1 && krow >= N) {   // wave-uniform: 16 all-padding keys
-                    dsv[1] = f32x4{0, 0, 0, 0};
-                    continue;
-                }
                 f32x4 sa = f32x4{0, 0, 0, 0}, da = f32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
