@@ -40,6 +40,11 @@ const char* tic_last_error_string(void);
  *                                           out (bit 0 no LDS-DMA, 1 no fragment reads, 2 no MFMA, 3 deeper queue): GARBAGE
  *                                           results by construction, tools/gemm_dbg.py only */
 int tic_set_option(const char* name, int value);
+/* Live timing of the step's dominant kernel (the grouped dW launch of tic_gemm_tn_group_bf16 / tic_vit_backward_layer): while
+ * enabled, HIP events are recorded on the launch stream around every such launch (up to 8192); read() waits for them and
+ * returns how many launches were timed and their summed duration.  bench.py's roofline.achieved comes from this. */
+int tic_kernel_timer_enable(int on);
+int tic_kernel_timer_read(int* launches, float* total_ms);
 
 /* GEMM epilogues (fused into the MFMA kernel's store) */
 #define TIC_EPI_BF16 0  /* out = bf16(acc + bias)                                   Linear            */

@@ -13,7 +13,7 @@ for (M, N, K) in ((32702, 3072, 1024), (32702, 4096, 4096)):
     W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device=dev)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    for dbg in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14):
+    for dbg in (0, 16, 17, 18, 19, 24):
         call("tic_set_option", b"gemm_dbg", dbg)
         def run():
             call("tic_gemm_nt_bf16", A.data_ptr(), W.data_ptr(), M, N, K, 0, bias.data_ptr(), out.data_ptr(), None, None, None, None, None, 0, current_stream())
@@ -26,7 +26,7 @@ for (M, N, K) in ((32702, 3072, 1024), (32702, 4096, 4096)):
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
-        print(f"M={M} N={N} K={K} dbg={dbg} ({'noDMA ' if dbg&1 else ''}{'noLDSread ' if dbg&2 else ''}{'noMFMA ' if dbg&4 else ''}{'vmcnt12' if dbg&8 else ''}): {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF-equivalent", flush=True)
+        print(f"M={M} N={N} K={K} dbg={dbg} ({'noDMA ' if dbg&1 else ''}{'noLDSread ' if dbg&2 else ''}{'noMFMA ' if dbg&4 else ''}{'vmcnt12 ' if dbg&8 else ''}{'1barrier/phase' if dbg&16 else ''}): {us:8.1f} us  {2.0*M*N*K/us/1e6:7.1f} TF-equivalent", flush=True)
 call("tic_set_option", b"gemm_dbg", 0)
 
 # the same isolation for the dW (TN) kernel: one 4096 x 4096 problem = 256 tiles, one per CU, full reduction over M
@@ -36,7 +36,7 @@ M, N, K = 32702, 4096, 4096
 A = torch.randn(M, N, device=dev).to(torch.bfloat16); B = torch.randn(M, K, device=dev).to(torch.bfloat16); C = torch.zeros(N, K, device=dev)
 PA = (ctypes.c_void_p * 1)(A.data_ptr()); PB = (ctypes.c_void_p * 1)(B.data_ptr()); PC = (ctypes.c_void_p * 1)(C.data_ptr())
 NN = (ctypes.c_int * 1)(N); KK = (ctypes.c_int * 1)(K)
-for dbg in (0, 1, 2, 3, 4, 5, 6, 7):
+for dbg in (0,):
     call("tic_set_option", b"gemm_dbg", dbg)
     def run():
         call("tic_gemm_tn_group_bf16", 1, PA, PB, PC, NN, KK, M, current_stream())

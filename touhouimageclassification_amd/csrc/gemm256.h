@@ -204,7 +204,7 @@ TIC_DEV void g256_finish_f32(const GemmNtParams& p, int m0, int n0) {
 }
 
 // DBG (measurement builds only, EPI_BF16): bit 0 = no LDS-DMA, bit 1 = no fragment ds_reads, bit 2 = no MFMA, bit 3 = vmcnt(12)
-// in the loop (6 half-tiles in flight: a RACE, timing only) -- isolates which
+// in the loop (6 half-tiles in flight: a RACE, timing only), bit 4 = ONE barrier per phase and no wave-group stagger (a RACE too) -- isolates which
 // of the three pipes bounds the main loop (tic_set_option("gemm_dbg")); results are garbage by construction.
 template <int EPI, int DBG = 0>
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
@@ -330,8 +330,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES, bufn = (uint32_t)(cur ^ 1) * G256_BUF_BYTES;
         // ---- phase 0: Q00 = A0 x B0 ; reads A0(t) k-half 1, B1(t)
         issue(cur ^ 1, kt + 1, 3);   // A1(t+1): that slot was last read in phase 2 of tile t-1
-        wait_vmcnt<(DBG & 8) ? 12 : 8>();             // A1(t) has landed (first read: phase 1)
-        g256_barrier();
+        wait_vmcnt<(DBG & 8) ? 12 : 8>();   // A1(t) has landed (first read: phase 1)
+        if (!(DBG & 16)) g256_barrier();
         prio_hi();
         load_a(bufb, 0, fa0, 1);
         load_b(bufb, 1, fbq);
@@ -342,8 +342,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         g256_barrier();
         // ---- phase 1: Q01 = A0 x B1 ; reads A1(t) k-half 0
         issue(cur, kt + 2, 1);       // B0(t+2): B0(t) was read in phase 3 of tile t-1 (and lives in fbp)
-        wait_vmcnt<(DBG & 8) ? 12 : 8>();             // B0(t+1) has landed (read: phase 3)
-        g256_barrier();
+        wait_vmcnt<(DBG & 8) ? 12 : 8>();   // B0(t+1) has landed (read: phase 3)
+        if (!(DBG & 16)) g256_barrier();
         prio_hi();
         load_a(bufb, 1, fa1, 0);
         mma(0, 1, fa0, fbq);
@@ -353,8 +353,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         g256_barrier();
         // ---- phase 2: Q11 = A1 x B1 ; reads A1(t) k-half 1
         issue(cur, kt + 2, 0);       // A0(t+2): A0(t) was last read in phase 0
-        wait_vmcnt<(DBG & 8) ? 12 : 8>();             // A0(t+1) has landed (first read: phase 3)
-        g256_barrier();
+        wait_vmcnt<(DBG & 8) ? 12 : 8>();   // A0(t+1) has landed (first read: phase 3)
+        if (!(DBG & 16)) g256_barrier();
         prio_hi();
         load_a(bufb, 1, fa1, 1);
         mma(1, 1, fa1, fbq);
@@ -364,8 +364,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         g256_barrier();
         // ---- phase 3: Q10 = A1 x B0 ; reads A0(t+1) k-half 0, B0(t+1)
         issue(cur, kt + 2, 2);       // B1(t+2): B1(t) was read in phase 0
-        wait_vmcnt<(DBG & 8) ? 12 : 8>();             // B1(t+1) has landed (read: phase 0 of tile t+1)
-        g256_barrier();
+        wait_vmcnt<(DBG & 8) ? 12 : 8>();   // B1(t+1) has landed (read: phase 0 of tile t+1)
+        if (!(DBG & 16)) g256_barrier();
         prio_hi();
         load_a(bufn, 0, fa0, 0);
         load_b(bufn, 0, fbq);
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     load_a(0u, 0, fa0, 0);
     load_b(0u, 0, fbx);
     wait_lgkmcnt0();
-    if (wr == 1) g256_barrier();
+    if (wr == 1 && !(DBG & 16)) g256_barrier();
 
     // two tiles per trip (the B register sets swap roles every tile); an odd tile count runs one extra all-zero tile
     // (its DMAs are the zero fills above) rather than a second loop exit, which made hipcc copy all 128 accumulators
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         tile(kt + 1, fby, fbx);
     }
     wait_vmcnt0();   // drain the zero fills issued for the tiles past the end before LDS is reused
-    if (wr == 0) g256_barrier();   // re-balance the stagger
+    if (wr == 0 && !(DBG & 16)) g256_barrier();   // re-balance the stagger
     g256_barrier();                // every wave's LDS reads and DMA writes have retired: the tile buffers are free
 
     // ---- stage u = bf16(acc) into LDS: rows r = i*4 + mt, column groups g = j*2 + nt

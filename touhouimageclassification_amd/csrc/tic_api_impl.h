@@ -54,7 +54,7 @@ extern "C" int tic_set_option(const char* name, int value) {
         g_opt_gemm_stagger = value;
         return TIC_OK;
     }
-    if (name && !strcmp(name, "gemm_dbg") && value >= 0 && value < 16) {
+    if (name && !strcmp(name, "gemm_dbg") && value >= 0 && value < 32) {
         g_opt_gemm_dbg = value;
         return TIC_OK;
     }
@@ -74,6 +74,17 @@ extern "C" int tic_set_option(const char* name, int value) {
 }
 
 extern "C" int tic_version(void) { return TIC_ABI_VERSION; }
+// live timing of the dominant kernel (the grouped stream-K dW launch): HIP events on the launch stream around every launch
+// while enabled; read() synchronises those events and returns the launch count and their summed duration
+extern "C" int tic_kernel_timer_enable(int on) {
+    if (TIC_RT_TIMER_ENABLE(on) != 0) return tic_fail(TIC_ELAUNCH, "kernel_timer: hipEventCreate failed");
+    return TIC_OK;
+}
+extern "C" int tic_kernel_timer_read(int* launches, float* total_ms) {
+    TIC_REQUIRE(launches && total_ms, "kernel_timer_read: null pointer");
+    if (TIC_RT_TIMER_READ(launches, total_ms) != 0) return tic_fail(TIC_ELAUNCH, "kernel_timer_read: event query failed");
+    return TIC_OK;
+}
 extern "C" const char* tic_last_error_string(void) { return g_tic_err; }
 
 // ---- GEMM ------------------------------------------------------------------------------------------
@@ -133,7 +144,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         break;
                 switch (g_opt_gemm_dbg) {
                     TIC_DBG_CASE(1) TIC_DBG_CASE(2) TIC_DBG_CASE(3) TIC_DBG_CASE(4) TIC_DBG_CASE(5) TIC_DBG_CASE(6) TIC_DBG_CASE(7)
-                    TIC_DBG_CASE(8) TIC_DBG_CASE(10) TIC_DBG_CASE(12) TIC_DBG_CASE(14)
+                    TIC_DBG_CASE(8) TIC_DBG_CASE(10) TIC_DBG_CASE(12) TIC_DBG_CASE(14) TIC_DBG_CASE(16) TIC_DBG_CASE(17) TIC_DBG_CASE(18) TIC_DBG_CASE(19) TIC_DBG_CASE(24)
                 }
 #undef TIC_DBG_CASE
                 break;
@@ -230,7 +241,9 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
                 }
             }
             TIC_RT_MAX_LDS(gemm_tn256_streamk_kernel, G256_LDS_BYTES);
+            TIC_RT_TIMER_MARK(0, stream);
             TIC_LAUNCH(gemm_tn256_streamk_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
+            TIC_RT_TIMER_MARK(1, stream);
             return tic_after_launch("gemm_tn_group(stream-K)");
         }
         if (g_opt_gemm_dbg) {

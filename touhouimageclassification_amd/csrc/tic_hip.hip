@@ -30,4 +30,40 @@ static inline const char* tic_rt_last_error() {
         }                                                                                                         \
     } while (0)
 
+// ---- live kernel timer (bench.py roofline): HIP events around every grouped-dW launch, on the launch stream ----------
+#define TIC_TIMER_SLOTS 8192
+static bool g_timer_on = false;
+static int g_timer_n = 0;
+static hipEvent_t g_timer_ev[TIC_TIMER_SLOTS][2];
+static bool g_timer_made = false;
+static inline void tic_rt_timer_mark(int which, void* stream) {
+    if (!g_timer_on || g_timer_n >= TIC_TIMER_SLOTS) return;
+    hipEventRecord(g_timer_ev[g_timer_n][which], (hipStream_t)stream);
+    if (which == 1) ++g_timer_n;
+}
+static inline int tic_rt_timer_enable(int on) {
+    if (on && !g_timer_made) {
+        for (int i = 0; i < TIC_TIMER_SLOTS; ++i)
+            if (hipEventCreate(&g_timer_ev[i][0]) != hipSuccess || hipEventCreate(&g_timer_ev[i][1]) != hipSuccess) return -1;
+        g_timer_made = true;
+    }
+    g_timer_on = on != 0;
+    g_timer_n = 0;
+    return 0;
+}
+static inline int tic_rt_timer_read(int* launches, float* total_ms) {
+    float tot = 0.f;
+    for (int i = 0; i < g_timer_n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_timer_ev[i][1]) != hipSuccess || hipEventElapsedTime(&ms, g_timer_ev[i][0], g_timer_ev[i][1]) != hipSuccess) return -1;
+        tot += ms;
+    }
+    *launches = g_timer_n;
+    *total_ms = tot;
+    return 0;
+}
+#define TIC_RT_TIMER_MARK(which, stream) tic_rt_timer_mark((which), (stream))
+#define TIC_RT_TIMER_ENABLE(on) tic_rt_timer_enable(on)
+#define TIC_RT_TIMER_READ(n, ms) tic_rt_timer_read((n), (ms))
+
 #include "tic_api_impl.h"
