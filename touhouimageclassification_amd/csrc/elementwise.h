@@ -105,14 +105,15 @@ __global__ void __launch_bounds__(256) cast_transpose_kernel(const float* __rest
 }
 
 // flat AdamW over n4*4 elements; optional bf16 shadow of the updated parameters
+template <bool NT = false>
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, bf16_t* w16, long n4, float lr, float b1, float b2,
                                                      float eps, float wd, float inv_bc1, float inv_sqrt_bc2) {
     for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < n4; i += (long)TIC_NBLK_X * 256) {
-        f32x4 pv = *reinterpret_cast<const f32x4*>(p + i * 4);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
-        f32x4 mv = *reinterpret_cast<const f32x4*>(m + i * 4);
-        f32x4 vv = *reinterpret_cast<const f32x4*>(v + i * 4);
+        f32x4 pv = ld_f4<NT>(p + i * 4);
+        const f32x4 gv = ld_f4<NT>(g + i * 4);
+        f32x4 mv = ld_f4<NT>(m + i * 4);
+        f32x4 vv = ld_f4<NT>(v + i * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             pv[r] *= (1.0f - lr * wd);
@@ -121,10 +122,10 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
             const float denom = sqrtf(vv[r]) * inv_sqrt_bc2 + eps;
             pv[r] -= (lr * inv_bc1) * (mv[r] / denom);
         }
-        *reinterpret_cast<f32x4*>(p + i * 4) = pv;
-        *reinterpret_cast<f32x4*>(m + i * 4) = mv;
-        *reinterpret_cast<f32x4*>(v + i * 4) = vv;
-        if (w16) *reinterpret_cast<u32x2*>(w16 + i * 4) = u32x2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+        st_f4<NT>(p + i * 4, pv);
+        st_f4<NT>(m + i * 4, mv);
+        st_f4<NT>(v + i * 4, vv);
+        if (w16) *reinterpret_cast<u32x2*>(w16 + i * 4) = u32x2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};   // re-read by the next forward
     }
 }
 

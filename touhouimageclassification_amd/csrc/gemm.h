@@ -39,6 +39,7 @@ struct GemmNtParams {
     int patches;             // P (PATCH)
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the consumer), BF16 / DGELU
     ConvGather cg;           // gemm_nt_kernel<EPI, true> only
+    int nt;                  // 256x256 staged epilogue: bit 0 non-temporal output stores, bit 1 non-temporal operand loads
     int stagger;             // experiment (tic_set_option "gemm_stagger"): s_sleep rounds for every other first-wave workgroup
 };
 

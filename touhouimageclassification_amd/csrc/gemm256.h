@@ -75,7 +75,7 @@ TIC_DEV float bf_hi(uint32_t u) {
 }
 
 // 8 columns per thread: the bf16-output epilogues.  c16 = tid & 31, rows (tid >> 5) + 16 k.
-template <int EPI>
+template <int EPI, bool NTS, bool NTL>
 TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
     constexpr bool HAS_AUX = (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
     constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
@@ -90,7 +90,7 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int m = m0 + (b * PF + i) * 16 + rsub;
-                aux[b & 1][i] = (m < p.M) ? *reinterpret_cast<const u32x4*>(p.aux + (size_t)m * p.N + n) : u32x4{0u, 0u, 0u, 0u};
+                aux[b & 1][i] = (m < p.M) ? ld_u4<NTL>(p.aux + (size_t)m * p.N + n) : u32x4{0u, 0u, 0u, 0u};
             }
         }
     };
@@ -106,7 +106,7 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
             if (m >= p.M) continue;
             const size_t o = (size_t)m * p.N + n;
             if (EPI == TIC_EPI_BF16) {
-                *reinterpret_cast<u32x4*>(p.out + o) = u;
+                st_u4<NTS>(p.out + o, u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     cs[2 * j] += bf_lo(u[j]);
@@ -116,8 +116,8 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
                 u32x4 g;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) g[j] = pack2bf(gelu_erf(bf_lo(u[j])), gelu_erf(bf_hi(u[j])));
-                *reinterpret_cast<u32x4*>(p.out + o) = u;
-                *reinterpret_cast<u32x4*>(p.out2 + o) = g;
+                st_u4<NTS>(p.out + o, u);
+                st_u4<NTS>(p.out2 + o, g);
             } else if (EPI == TIC_EPI_GELU_DG) {
                 u32x4 g, dg;
 #pragma unroll
@@ -126,8 +126,8 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
                     g[j] = pack2bf(r.g[0], r.g[1]);
                     dg[j] = pack2bf(r.dg[0], r.dg[1]);
                 }
-                *reinterpret_cast<u32x4*>(p.out + o) = dg;
-                *reinterpret_cast<u32x4*>(p.out2 + o) = g;
+                st_u4<NTS>(p.out + o, dg);
+                st_u4<NTS>(p.out2 + o, g);
             } else {   // DGELU / MULAUX
                 const u32x4 a = aux[b & 1][i];
                 u32x4 d;
@@ -140,7 +140,7 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
                     cs[2 * j] += d0;
                     cs[2 * j + 1] += d1;
                 }
-                *reinterpret_cast<u32x4*>(p.out + o) = d;
+                st_u4<NTS>(p.out + o, d);
             }
         }
     }
@@ -164,7 +164,7 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
 }
 
 // 4 columns per thread: the fp32-output epilogues (RESID, PATCH).  c8 = tid & 63, rows (tid >> 6) + 8 k.
-template <int EPI>
+template <int EPI, bool NTS, bool NTL>
 TIC_DEV void g256_finish_f32(const GemmNtParams& p, int m0, int n0) {
     constexpr int PF = 4;
     const int tid = TIC_TID, c8 = tid & 63, rsub = tid >> 6;
@@ -178,7 +178,7 @@ TIC_DEV void g256_finish_f32(const GemmNtParams& p, int m0, int n0) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int m = m0 + (b * PF + i) * 8 + rsub;
-            ex[b & 1][i] = (m < p.M) ? *reinterpret_cast<const f32x4*>(src_of(m)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ex[b & 1][i] = (m < p.M) ? ld_f4<NTL && EPI == TIC_EPI_RESID>(src_of(m)) : f32x4{0.f, 0.f, 0.f, 0.f};   // the position table is re-read: never NT
         }
     };
     fetch(0);
@@ -198,7 +198,7 @@ TIC_DEV void g256_finish_f32(const GemmNtParams& p, int m0, int n0) {
                 const int img = m / p.patches;
                 orow = (size_t)img * (p.patches + 1) + 1 + (m - img * p.patches);
             }
-            *reinterpret_cast<f32x4*>(p.out_f32 + orow * p.N + n) = y;
+            st_f4<NTS>(p.out_f32 + orow * p.N + n, y);
         }
     }
 }
@@ -416,8 +416,17 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     }
     block_sync();
     sched_fence();   // keep the second pass (and its operand prefetch) below the staging pass: the accumulators are dead from here
+    // kernel-argument (block-uniform) choice of the cache policy of the second pass
+#define G256_FINISH(FN)                                                   \
+    do {                                                                  \
+        if (p.nt == 0) FN<EPI, false, false>(p, m0, n0);                  \
+        else if (p.nt == 1) FN<EPI, true, false>(p, m0, n0);              \
+        else if (p.nt == 2) FN<EPI, false, true>(p, m0, n0);              \
+        else FN<EPI, true, true>(p, m0, n0);                              \
+    } while (0)
     if (EPI == TIC_EPI_RESID || EPI == TIC_EPI_PATCH)
-        g256_finish_f32<EPI>(p, m0, n0);
+        G256_FINISH(g256_finish_f32);
     else
-        g256_finish_bf16<EPI>(p, m0, n0);
+        G256_FINISH(g256_finish_bf16);
+#undef G256_FINISH
 }

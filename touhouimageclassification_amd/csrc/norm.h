@@ -17,7 +17,7 @@ TIC_DEV float wave_sum(float v) {
 }
 
 // NV = ceil(D / 256): float4 groups per lane.  in_stride: elements between consecutive rows of x.
-template <int NV>
+template <int NV, bool NT = false>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x, long in_stride,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       bf16_t* __restrict__ y, float* __restrict__ mean_out,
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + l) * 4;
             if (c < D) {
-                v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+                v[i] = ld_f4<NT>(xr + c);
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             } else {
                 v[i] = f32x4{0, 0, 0, 0};
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - mu) * rs * gm[i][r] + bt[i][r];
-                *reinterpret_cast<u32x2*>(y + (long)row * D + c) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                st_u2<NT>(y + (long)row * D + c, u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])});
             }
         }
         if (l == 0) {
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
 // dx = (dres ? dres : 0) + LN'(dy).  dgamma / dbeta: fp32 [D], accumulated with atomics.
 // colsum (optional, fp32 [D]) += column sums of dx = the bias gradient of the Linear whose output gradient dx is.
 // LDS: 3 * 4 * D floats.
-template <int NV>
+template <int NV, bool NT = false>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, long stride,
                                                       const float* __restrict__ gamma, const float* __restrict__ mean_in,
                                                       const float* __restrict__ rstd_in, const float* dres, float* dx,
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + l) * 4;
             if (c < D) {
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+                const f32x4 xv = ld_f4<NT>(xr + c);
                 const u32x2 dr = *reinterpret_cast<const u32x2*>(dy + (long)row * D + c);
                 const float d[4] = {bf2f((bf16_t)(dr[0] & 0xffff)), bf2f((bf16_t)(dr[0] >> 16)),
                                     bf2f((bf16_t)(dr[1] & 0xffff)), bf2f((bf16_t)(dr[1] >> 16))};
@@ -138,10 +138,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = rs * (g[i][r] - c1 - xh[i][r] * c2);
                 const long off = (long)row * stride + c;
-                if (dres) o += *reinterpret_cast<const f32x4*>(dres + off);
-                *reinterpret_cast<f32x4*>(dx + off) = o;
+                if (dres) o += ld_f4<NT>(dres + off);
+                st_f4<NT>(dx + off, o);
                 dc[i] += o;
-                if (dxb) *reinterpret_cast<u32x2*>(dxb + off) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                if (dxb) st_u2<NT>(dxb + off, u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])});
             }
         }
     }

@@ -45,11 +45,16 @@ static int tic_after_launch(const char* what) {
 // tuning knobs (process-wide, for A/B measurements and tests): "gemm_tile" = 0 (auto) | 128 | 256 ;
 // "tn_streamk" = 1 (default: grouped dW as 256 equal stream-K shares) | 0 (one workgroup per full-M tile)
 static int g_opt_gemm_tile = 0;
+static int g_opt_nt = 1;          // non-temporal loads / stores for once-touched streams: 1 LayerNorm (-0.45 % step), 2 AdamW, 4 GEMM epilogue stores, 8 GEMM epilogue operand loads
 static int g_opt_gemm_dbg = 0;
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 extern "C" int tic_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
+        g_opt_nt = value;
+        return TIC_OK;
+    }
     if (name && !strcmp(name, "gemm_stagger") && value >= -1 && value <= 64) {
         g_opt_gemm_stagger = value;
         return TIC_OK;
@@ -123,6 +128,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     // (tools/stagger_probe.py); inside the training step the gain is zero (tools/ab_step.py gemm_stagger 0 2: 141.8 vs
     // 141.9 ms) -- there the previous kernel's tail already starts the CUs at different times.
     p.stagger = g_opt_gemm_stagger > 0 ? g_opt_gemm_stagger : 0;
+    p.nt = (g_opt_nt >> 2) & 3;
 #define TIC_GEMM_NT_LAUNCH(E)                                                                        \
     do {                                                                                             \
         if (big) {                                                                                   \
@@ -280,7 +286,11 @@ extern "C" int tic_layernorm_fwd(const float* x, long in_stride, const float* ga
     TIC_REQUIRE(x && gamma && beta && y_bf16 && mean && rstd, "layernorm_fwd: null pointer");
     TIC_REQUIRE(rows >= 1 && D >= 4 && D % 4 == 0 && D <= 1024 && in_stride % 4 == 0, "layernorm_fwd: need D %% 4 == 0, D <= 1024 (D=%d)", D);
     const int nv = (D + 255) / 256, grid = ln_grid(rows);
-#define TIC_LN_FWD(NV) TIC_LAUNCH(ln_fwd_kernel<NV>, grid, 256, 0, stream, x, in_stride, gamma, beta, (bf16_t*)y_bf16, mean, rstd, rows, D, eps)
+#define TIC_LN_FWD(NV)                                                                                                                   \
+    do {                                                                                                                                 \
+        if (g_opt_nt & 1) TIC_LAUNCH((ln_fwd_kernel<NV, true>), grid, 256, 0, stream, x, in_stride, gamma, beta, (bf16_t*)y_bf16, mean, rstd, rows, D, eps); \
+        else TIC_LAUNCH((ln_fwd_kernel<NV, false>), grid, 256, 0, stream, x, in_stride, gamma, beta, (bf16_t*)y_bf16, mean, rstd, rows, D, eps);          \
+    } while (0)
     if (nv == 1) TIC_LN_FWD(1); else if (nv == 2) TIC_LN_FWD(2); else if (nv == 3) TIC_LN_FWD(3); else TIC_LN_FWD(4);
 #undef TIC_LN_FWD
     return tic_after_launch("layernorm_fwd");
@@ -299,7 +309,11 @@ extern "C" int tic_layernorm_bwd_ex(const void* dy_bf16, const float* x, long st
     int grid = ln_grid(rows);
     if (grid > 512) grid = 512;   // fewer, longer blocks: one dgamma/dbeta atomic row per block
     const size_t lds = (size_t)3 * 4 * D * 4;
-#define TIC_LN_BWD(NV) TIC_LAUNCH(ln_bwd_kernel<NV>, grid, 256, lds, stream, (const bf16_t*)dy_bf16, x, stride, gamma, mean, rstd, dres, dx, (bf16_t*)dxb_bf16, dgamma, dbeta, colsum, rows, D)
+#define TIC_LN_BWD(NV)                                                                                                                   \
+    do {                                                                                                                                 \
+        if (g_opt_nt & 1) TIC_LAUNCH((ln_bwd_kernel<NV, true>), grid, 256, lds, stream, (const bf16_t*)dy_bf16, x, stride, gamma, mean, rstd, dres, dx, (bf16_t*)dxb_bf16, dgamma, dbeta, colsum, rows, D); \
+        else TIC_LAUNCH((ln_bwd_kernel<NV, false>), grid, 256, lds, stream, (const bf16_t*)dy_bf16, x, stride, gamma, mean, rstd, dres, dx, (bf16_t*)dxb_bf16, dgamma, dbeta, colsum, rows, D);          \
+    } while (0)
     if (nv == 1) TIC_LN_BWD(1); else if (nv == 2) TIC_LN_BWD(2); else if (nv == 3) TIC_LN_BWD(3); else TIC_LN_BWD(4);
 #undef TIC_LN_BWD
     return tic_after_launch("layernorm_bwd");
@@ -394,8 +408,11 @@ extern "C" int tic_adamw(float* p, const float* g, float* m, float* v, void* w16
                          float beta2, float eps, float weight_decay, int step, tic_stream_t stream) {
     TIC_REQUIRE(p && g && m && v && n >= 4 && n % 4 == 0 && step >= 1, "adamw: need n %% 4 == 0 and step >= 1");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    TIC_LAUNCH(adamw_kernel, ew_grid(n / 4), 256, 0, stream, p, g, m, v, (bf16_t*)w16, n / 4, lr, beta1, beta2, eps,
-               weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+    const float inv_bc1 = (float)(1.0 / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    if (g_opt_nt & 2)
+        TIC_LAUNCH(adamw_kernel<true>, ew_grid(n / 4), 256, 0, stream, p, g, m, v, (bf16_t*)w16, n / 4, lr, beta1, beta2, eps, weight_decay, inv_bc1, inv_sqrt_bc2);
+    else
+        TIC_LAUNCH(adamw_kernel<false>, ew_grid(n / 4), 256, 0, stream, p, g, m, v, (bf16_t*)w16, n / 4, lr, beta1, beta2, eps, weight_decay, inv_bc1, inv_sqrt_bc2);
     return tic_after_launch("adamw");
 }
 extern "C" int tic_head_fwd(const void* z_bf16, const float* W, const float* bias, float* logits, int B, int C, int D,

@@ -163,6 +163,38 @@ TIC_DEV uint32_t pack2bf(float lo, float hi) {   // ONE v_cvt_pk_bf16_f32 (two s
 }
 #endif
 
+// streaming accesses: data touched once per pass (the fp32 residual stream and its gradient); NT = non-temporal hint
+template <bool NT> TIC_DEV f32x4 ld_f4(const float* p) {
+#ifndef TIC_SIM
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#endif
+    return *reinterpret_cast<const f32x4*>(p);
+}
+template <bool NT> TIC_DEV void st_f4(float* p, f32x4 v) {
+#ifndef TIC_SIM
+    if (NT) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); return; }
+#endif
+    *reinterpret_cast<f32x4*>(p) = v;
+}
+template <bool NT> TIC_DEV void st_u2(bf16_t* p, u32x2 v) {
+#ifndef TIC_SIM
+    if (NT) { __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p)); return; }
+#endif
+    *reinterpret_cast<u32x2*>(p) = v;
+}
+template <bool NT> TIC_DEV u32x4 ld_u4(const bf16_t* p) {
+#ifndef TIC_SIM
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#endif
+    return *reinterpret_cast<const u32x4*>(p);
+}
+template <bool NT> TIC_DEV void st_u4(bf16_t* p, u32x4 v) {
+#ifndef TIC_SIM
+    if (NT) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); return; }
+#endif
+    *reinterpret_cast<u32x4*>(p) = v;
+}
+
 // exact-erf GELU (HF activations.py:83) and its derivative, with erfc evaluated by the
 // Abramowitz-Stegun 7.1.26 rational form: erfc(z) = P(t) exp(-z^2), t = 1/(1 + 0.3275911 z), z >= 0,
 // |abs error| <= 1.5e-7 -- three orders below the bf16 rounding applied to every value these feed.
