@@ -45,7 +45,8 @@ static int tic_after_launch(const char* what) {
 // tuning knobs (process-wide, for A/B measurements and tests): "gemm_tile" = 0 (auto) | 128 | 256 ;
 // "tn_streamk" = 1 (default: grouped dW as 256 equal stream-K shares) | 0 (one workgroup per full-M tile)
 static int g_opt_gemm_tile = 0;
-static int g_opt_nt = 1;          // non-temporal loads / stores for once-touched streams: 1 LayerNorm (-0.45 % step), 2 AdamW, 4 GEMM epilogue stores, 8 GEMM epilogue operand loads
+static int g_opt_nt = 13;         // non-temporal loads / stores for once-touched streams (tools/ab_step.py stream_nt a b): 1 LayerNorm (-0.45 % step),
+                                  // 2 AdamW (no effect: off), 4 staged GEMM epilogue stores (-0.8 %), 8 its residual / derivative operand loads (-0.1 %)
 static int g_opt_gemm_dbg = 0;
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
