@@ -40,6 +40,7 @@ struct GemmNtParams {
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the consumer), BF16 / DGELU
     ConvGather cg;           // gemm_nt_kernel<EPI, true> only
     int nt;                  // 256x256 staged epilogue: bit 0 non-temporal output stores, bit 1 non-temporal operand loads
+    int gm;                  // m-tiles per group of the XCD-local tile walk (tile_coords), 0 = 8
     int stagger;             // experiment (tic_set_option "gemm_stagger"): s_sleep rounds for every other first-wave workgroup
 };
 
@@ -49,10 +50,9 @@ TIC_DEV uint32_t swz128(uint32_t row) { return ((row >> 1) & 3u) << 1; }
 
 // XCD-aware, grouped tile order: blocks that share an XCD (bid % 8, guide T1) get a contiguous
 // range of tiles, walked GM m-tiles at a time so A and B panels are re-read from that XCD's L2.
-TIC_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+TIC_DEV void tile_coords(int bid, int nwg, int tiles_m, int tiles_n, int& tm, int& tn, int GM = 8) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int GM = 8;
     const int per_group = GM * tiles_n;
     const int group = wg / per_group;
     const int first_m = group * GM;

@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     const int wr = w >> 2, wc = w & 3;
     const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / 256;
     int tm, tn;
-    tile_coords(TIC_BID_X, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
+    tile_coords(TIC_BID_X, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn, p.gm > 0 ? p.gm : 8);
     const int m0 = tm * 256, n0 = tn * 256;
 #ifndef TIC_SIM
     // experiment: delay every other workgroup of the first wave of tiles so that epilogues (HBM bursts) of one half of the

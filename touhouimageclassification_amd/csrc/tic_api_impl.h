@@ -47,11 +47,21 @@ static int tic_after_launch(const char* what) {
 static int g_opt_gemm_tile = 0;
 static int g_opt_nt = 13;         // non-temporal loads / stores for once-touched streams (tools/ab_step.py stream_nt a b): 1 LayerNorm (-0.45 % step),
                                   // 2 AdamW (no effect: off), 4 staged GEMM epilogue stores (-0.8 %), 8 its residual / derivative operand loads (-0.1 %)
+static int g_opt_ln_blocks = 4096;   // grid cap of the LayerNorm kernels (4 rows per block per pass)
+static int g_opt_gemm_gm = 8;
 static int g_opt_gemm_dbg = 0;
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 extern "C" int tic_set_option(const char* name, int value) {
+    if (name && !strcmp(name, "ln_blocks") && value >= 64 && value <= 65536) {
+        g_opt_ln_blocks = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "gemm_gm") && value >= 1 && value <= 256) {
+        g_opt_gemm_gm = value;
+        return TIC_OK;
+    }
     if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
         g_opt_nt = value;
         return TIC_OK;
@@ -130,6 +140,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     // 141.9 ms) -- there the previous kernel's tail already starts the CUs at different times.
     p.stagger = g_opt_gemm_stagger > 0 ? g_opt_gemm_stagger : 0;
     p.nt = (g_opt_nt >> 2) & 3;
+    p.gm = g_opt_gemm_gm;
 #define TIC_GEMM_NT_LAUNCH(E)                                                                        \
     do {                                                                                             \
         if (big) {                                                                                   \
@@ -280,7 +291,7 @@ extern "C" int tic_layernorm_bwd_ex(const void* dy_bf16, const float* x, long st
                                     float* dbeta, float* colsum, int rows, int D, tic_stream_t stream);
 static int ln_grid(int rows) {
     int g = (rows + 3) / 4;
-    return g > 2048 ? 2048 : (g < 1 ? 1 : g);
+    return g > g_opt_ln_blocks ? g_opt_ln_blocks : (g < 1 ? 1 : g);
 }
 extern "C" int tic_layernorm_fwd(const float* x, long in_stride, const float* gamma, const float* beta, void* y_bf16,
                                  float* mean, float* rstd, int rows, int D, float eps, tic_stream_t stream) {
