@@ -127,3 +127,41 @@ def test_headline_shape_properties():
     torch.nn.functional.cross_entropy(m(x).logits, y).backward()
     assert all(p.grad is None for p in m.base_model.parameters())
     assert m.classifier.weight.grad is not None and m.classifier.weight.grad.abs().sum() > 0
+
+
+def test_tiny_training_trajectory_tracks_oracle_and_overfits(golden_dir):
+    """several fused steps (forward, CE, backward, AdamW, bf16 weight refresh) on one fixed batch: the loss trajectory of
+    the HIP path follows the fp32 CPU oracle (autocast-emulating forward, torch AdamW arithmetic) step for step, and the
+    model overfits the batch -- the optimizer / weight-shadow plumbing is exercised over many steps, not one."""
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from touhouimageclassification_amd.step import fused_train_step
+    dev = torch.device("cuda")
+    gold = np.load(f"{golden_dir}/vit_tiny.npz")
+    spec = vo.ViTSpec(**vo.VIT_TINY, num_labels=10)
+    params = {k[len("param/"):]: torch.from_numpy(gold[k]).clone() for k in gold.files if k.startswith("param/")}
+    x, y = torch.from_numpy(gold["x"]), torch.from_numpy(gold["y"])
+    m = _model("tiny", 10, params, dev)
+    lr, steps = 1e-3, 6
+    opt = FusedAdamW(m, lr=lr, weight_decay=0.01)
+    hip_losses = []
+    for _ in range(steps):
+        loss, _ = fused_train_step(m, opt, x.to(dev), y.to(dev), None)
+        hip_losses.append(float(loss))
+    # oracle trajectory
+    ref = {k: v.clone() for k, v in params.items()}
+    mom = {k: torch.zeros_like(v) for k, v in ref.items()}
+    var = {k: torch.zeros_like(v) for k, v in ref.items()}
+    ref_losses = []
+    for t in range(1, steps + 1):
+        _, l, g = vo.loss_and_grads(ref, x, y, spec, emulate_autocast=True)
+        ref_losses.append(float(l))
+        for k in ref:
+            vo.adamw_step(ref[k], g[k], mom[k], var[k], t, lr)
+    assert abs(hip_losses[0] - ref_losses[0]) <= 1e-2 * ref_losses[0]
+    for a, b in zip(hip_losses, ref_losses):   # Adam's sign-like first steps amplify bf16 noise: the band widens with the step
+        assert abs(a - b) <= 0.08 * max(b, 0.2), (hip_losses, ref_losses)
+    assert ref_losses[-1] < 0.7 * ref_losses[0] and hip_losses[-1] < 0.7 * hip_losses[0], (hip_losses, ref_losses)
+    # keep going: the HIP path drives the loss on this batch towards zero
+    for _ in range(40):
+        loss, logits = fused_train_step(m, opt, x.to(dev), y.to(dev), None)
+    assert float(loss) < 0.05 and (logits.argmax(-1).cpu() == y).all(), float(loss)
