@@ -158,15 +158,8 @@ int tic_conv_weight_pack(const float* w_oihw, void* w16_ohwi, int Co, int Ci, in
  *   fwd   : y[B*Ho*Wo, Cout] (bf16) = conv(x, w)            -- also the stride-1 input gradient: call it with dY as x, Cin/Cout
  *           swapped, pad = k-1-pad and w_pack = tic_conv_weight_pack(..., transposed = 2) (flipped, channel-transposed filter)
  *   wgrad : dw[Cout, kh*kw*Cin] (fp32, tap-major, += with atomics) = dY^T . gather(x); fold into OIHW with tic_conv_weight_grad */
-int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, float* stats2c_or_null, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                        int stride, int pad, tic_stream_t stream);
-/* plain conv-as-GEMM (1x1 stride 1, or over an im2col buffer) with the BatchNorm batch statistics of the output fused into the
- * epilogue: sums[s][0..N) += column sums, sums[s][N..2N) += column sums of squares (of the stored bf16 values), s = workgroup mod
- * TIC_BN_STAT_SLOTS, sums = fp32 [TIC_BN_STAT_SLOTS][2N] zeroed by the caller; the same buffer shape is what stats2c of
- * tic_conv_igemm_fwd receives.  tic_batchnorm_fwd(train = 2) then skips its own statistics pass. */
-#define TIC_BN_STAT_SLOTS 64 /* the fused statistics are accumulated as 64 partial vectors [64][2N] (workgroup index mod 64):
-                                one vector would put tens of thousands of workgroups on the same 2N addresses */
-int tic_gemm_nt_stats_bf16(const void* A, const void* B, int M, int N, int K, void* out_bf16, float* sums2n, tic_stream_t stream);
 int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* dw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                          int stride, int pad, tic_stream_t stream);
 int tic_conv_weight_grad(const float* dw_ohwi, float* grad_oihw, int Co, int Ci, int kh, int kw, tic_stream_t stream); /* grad += */

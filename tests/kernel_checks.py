@@ -34,20 +34,6 @@ def check_gemm_nt_bias_bf16(env, M, N, K):
     torch.testing.assert_close(out.float(), ref, atol=0.06, rtol=0.02)
 
 
-def check_gemm_nt_stats(env, M, N, K):
-    """conv-as-GEMM with the BatchNorm statistics of the output fused: sums and sums of squares of the stored bf16 values"""
-    rnd, call, dev = env.rnd, env.call, env.dev
-    A, B = bf(rnd(M, K, scale=0.5)), bf(rnd(N, K, scale=0.2))
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    sums = torch.zeros(64, 2 * N, device=dev)   # TIC_BN_STAT_SLOTS partial vectors
-    sums[0] += 1
-    call("tic_gemm_nt_stats_bf16", ptr(A), ptr(B), M, N, K, ptr(out), ptr(sums), None)
-    sums = sums.sum(0)
-    torch.testing.assert_close(out.float(), A.float() @ B.float().t(), atol=0.06, rtol=0.02)
-    torch.testing.assert_close(sums[:N], 1 + out.float().sum(0), atol=2e-3 * M ** 0.5 + 1e-3, rtol=1e-4)
-    torch.testing.assert_close(sums[N:], 1 + (out.float() ** 2).sum(0), atol=2e-3 * M ** 0.5 + 1e-3, rtol=1e-4)
-
-
 def check_gemm_nt_gelu_resid_dgelu_patch(env, N=128, K=128, imgs=3, Pn=50):
     rnd, call, dev = env.rnd, env.call, env.dev
     M = imgs * Pn

@@ -107,12 +107,3 @@ def test_gemm_tn_group_phase_aligned_split(env):
     finally:
         call("tic_set_option", b"gemm_tile", 0)
         call("tic_set_option", b"tn_streamk", 1)
-
-
-@pytest.mark.parametrize("tile,M,N,K", [(128, 150, 192, 64), (256, 300, 256, 128), (256, 700, 512, 64)])
-def test_gemm_nt_fused_batchnorm_statistics(env, tile, M, N, K):
-    call("tic_set_option", b"gemm_tile", tile)
-    try:
-        kc.check_gemm_nt_stats(env, M, N, K)
-    finally:
-        call("tic_set_option", b"gemm_tile", 0)

@@ -118,12 +118,9 @@ class TicResNet(nn.Module):
     def _call(self, name, *args):
         self.backend.call(name, *args, self.backend.stream())
 
-    def _gemm_nt(self, A, Bw, M, N, K, stats=None):
+    def _gemm_nt(self, A, Bw, M, N, K):
         out = torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
-        if stats is not None:   # BatchNorm batch statistics of the output fused into the GEMM epilogue
-            self._call("tic_gemm_nt_stats_bf16", A.data_ptr(), Bw.data_ptr(), M, N, K, out.data_ptr(), stats.data_ptr())
-        else:
-            self._call("tic_gemm_nt_bf16", A.data_ptr(), Bw.data_ptr(), M, N, K, 0, None, out.data_ptr(), None, None, None, None, None, 0)
+        self._call("tic_gemm_nt_bf16", A.data_ptr(), Bw.data_ptr(), M, N, K, 0, None, out.data_ptr(), None, None, None, None, None, 0)
         return out
 
     def _pack(self, conv: _Conv, transposed):
@@ -148,29 +145,27 @@ class TicResNet(nn.Module):
         # 3x3 convolutions and the strided 1x1 downsample projections (a 1x1 stride-1 conv is a plain GEMM on the activation)
         return (conv.k > 1 or conv.stride > 1) and conv.cin % 64 == 0 and conv.cout % 8 == 0
 
-    def _conv_fwd(self, conv: _Conv, x, B, H, W, stats=None):
-        """x [B,H,W,Cin] bf16 -> (y [M,Cout] bf16, col or None, Ho, Wo); stats (fp32 [2*Cout], zeroed) receives sum / sum of squares of y"""
+    def _conv_fwd(self, conv: _Conv, x, B, H, W):
+        """x [B,H,W,Cin] bf16 -> (y [M,Cout] bf16, col or None, Ho, Wo)"""
         Ho = (H + 2 * conv.pad - conv.k) // conv.stride + 1
         Wo = (W + 2 * conv.pad - conv.k) // conv.stride + 1
         M = B * Ho * Wo
         if self._implicit(conv):   # 3x3: gather inside the GEMM, no im2col buffer (the backward gathers again from x)
             y = torch.empty(M, conv.cout, dtype=torch.bfloat16, device=x.device)
-            self._call("tic_conv_igemm_fwd", x.data_ptr(), self._pack(conv, 0).data_ptr(), y.data_ptr(), None if stats is None else stats.data_ptr(),
-                       B, H, W, conv.cin, conv.cout, conv.k, conv.k, conv.stride, conv.pad)
+            self._call("tic_conv_igemm_fwd", x.data_ptr(), self._pack(conv, 0).data_ptr(), y.data_ptr(), B, H, W, conv.cin, conv.cout,
+                       conv.k, conv.k, conv.stride, conv.pad)
             return y, x, Ho, Wo
         if conv.k == 1 and conv.stride == 1:
             col = x
         else:
             col = torch.empty(M, conv.kp, dtype=torch.bfloat16, device=x.device)
             self._call("tic_im2col_bf16", x.data_ptr(), col.data_ptr(), B, H, W, conv.cin, conv.k, conv.k, conv.stride, conv.pad)
-        return self._gemm_nt(col, self._pack(conv, 0), M, conv.cout, conv.kp, stats), col, Ho, Wo
+        return self._gemm_nt(col, self._pack(conv, 0), M, conv.cout, conv.kp), col, Ho, Wo
 
-    def _bn_fwd(self, bn: _BN, x, M, identity, relu, train, stats=None):
+    def _bn_fwd(self, bn: _BN, x, M, identity, relu, train):
         dev = x.device
         mean, rstd = torch.empty(bn.c, device=dev), torch.empty(bn.c, device=dev)
-        scratch = stats if stats is not None else torch.empty(2 * bn.c, device=dev)
-        if train and stats is not None:
-            train = 2   # the statistics are already in `stats` (fused into the conv GEMM epilogue)
+        scratch = torch.empty(2 * bn.c, device=dev)
         y = torch.empty_like(x)
         self._call("tic_batchnorm_fwd", x.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                    bn.num_batches_tracked.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(),
@@ -225,7 +220,7 @@ class TicResNet(nn.Module):
             Ho = (H + 2 * conv.pad - conv.k) // conv.stride + 1
             Wo = (W + 2 * conv.pad - conv.k) // conv.stride + 1
             dx = torch.empty(B * H * W, conv.cin, dtype=torch.bfloat16, device=dy.device)
-            self._call("tic_conv_igemm_fwd", dy.data_ptr(), self._pack(conv, 2).data_ptr(), dx.data_ptr(), None, B, Ho, Wo, conv.cout, conv.cin,
+            self._call("tic_conv_igemm_fwd", dy.data_ptr(), self._pack(conv, 2).data_ptr(), dx.data_ptr(), B, Ho, Wo, conv.cout, conv.cin,
                        conv.k, conv.k, 1, conv.k - 1 - conv.pad)
             return dx
         dcol = self._gemm_nt(dy, self._pack(conv, 1), M, conv.kp, conv.cout)
@@ -251,20 +246,6 @@ class TicResNet(nn.Module):
     def _blocks(self) -> List[_Block]:
         return [b for i in range(1, 5) for b in getattr(self, f"layer{i}")]
 
-    def _stats_slices(self, dev, train: bool):
-        """one flat fp32 buffer (zeroed by ONE fill per forward) whose slices receive each conv's fused BatchNorm statistics"""
-        if not train:
-            return None
-        bns = [m for m in self.modules() if isinstance(m, _BN)]
-        S = 64   # TIC_BN_STAT_SLOTS: partial vectors per layer (one vector = tens of thousands of workgroups on 2C addresses)
-        need = sum(S * 2 * b.c for b in bns)
-        flat = torch.zeros(need, dtype=torch.float32, device=dev)
-        out, off = {}, 0
-        for b in bns:
-            out[id(b)] = flat[off:off + S * 2 * b.c]
-            off += S * 2 * b.c
-        return out
-
     def _forward_impl(self, x: torch.Tensor, train: bool, record: bool):
         self.backend.check_tensor(x)
         B, C, H, W = x.shape
@@ -274,10 +255,8 @@ class TicResNet(nn.Module):
         tape: Dict = {"B": B, "blocks": []}
         xin = torch.empty(B, H, W, 3, dtype=torch.bfloat16, device=x.device)
         self._call("tic_nchw_to_nhwc_bf16", x.data_ptr(), xin.data_ptr(), B, 3, H, W)
-        st = self._stats_slices(x.device, train)
-        sof = (lambda bn: st[id(bn)]) if st is not None else (lambda bn: None)
-        c0, col0, H1, W1 = self._conv_fwd(self.conv1, xin, B, H, W, sof(self.bn1))
-        a0, m0, r0 = self._bn_fwd(self.bn1, c0, B * H1 * W1, None, True, train, sof(self.bn1))
+        c0, col0, H1, W1 = self._conv_fwd(self.conv1, xin, B, H, W)
+        a0, m0, r0 = self._bn_fwd(self.bn1, c0, B * H1 * W1, None, True, train)
         Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         h = torch.empty(B * Hp * Wp, 64, dtype=torch.bfloat16, device=x.device)
         self._call("tic_maxpool3x3s2_fwd", a0.data_ptr(), h.data_ptr(), B, H1, W1, 64)
@@ -287,8 +266,8 @@ class TicResNet(nn.Module):
             rec = {"in": h, "H": Hc, "W": Wc}
             convs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)] + ([(blk.conv3, blk.bn3)] if blk.kind == "bottleneck" else [])
             if blk.downsample is not None:
-                cd, cold, Hd, Wd = self._conv_fwd(blk.downsample[0], h, B, Hc, Wc, sof(blk.downsample[1]))
-                identity, md, rd = self._bn_fwd(blk.downsample[1], cd, B * Hd * Wd, None, False, train, sof(blk.downsample[1]))
+                cd, cold, Hd, Wd = self._conv_fwd(blk.downsample[0], h, B, Hc, Wc)
+                identity, md, rd = self._bn_fwd(blk.downsample[1], cd, B * Hd * Wd, None, False, train)
                 rec["ds"] = (cold, cd, md, rd)
             else:
                 identity = h
@@ -296,8 +275,8 @@ class TicResNet(nn.Module):
             steps = []
             for i, (cv, bn) in enumerate(convs):
                 last = i == len(convs) - 1
-                c, col, Ho, Wo = self._conv_fwd(cv, t, B, Ht, Wt, sof(bn))
-                y, m, r = self._bn_fwd(bn, c, B * Ho * Wo, identity if last else None, True, train, sof(bn))
+                c, col, Ho, Wo = self._conv_fwd(cv, t, B, Ht, Wt)
+                y, m, r = self._bn_fwd(bn, c, B * Ho * Wo, identity if last else None, True, train)
                 steps.append((col, c, y, m, r, Ht, Wt))
                 t, Ht, Wt = y, Ho, Wo
             rec["steps"] = steps

@@ -69,8 +69,7 @@ SIGNATURES = {
     "tic_mix_labels": ([P, P, I, I, F, P], I),
     "tic_conv_weight_pack": ([P, P, I, I, I, I, I, P], I),
     "tic_conv_weight_grad": ([P, P, I, I, I, I, P], I),
-    "tic_conv_igemm_fwd": ([P, P, P, P, I, I, I, I, I, I, I, I, I, P], I),
-    "tic_gemm_nt_stats_bf16": ([P, P, I, I, I, P, P, P], I),
+    "tic_conv_igemm_fwd": ([P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_conv_igemm_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_nchw_to_nhwc_bf16": ([P, P, I, I, I, I, P], I),
     "tic_im2col_bf16": ([P, P, I, I, I, I, I, I, I, I, P], I),

@@ -188,14 +188,8 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     const int c = TIC_BID_X * 256 + TIC_TID;
     if (c < C) {
         if (train) {
-            float s1 = 0.f, s2 = 0.f;   // train == 2: TIC_BN_STAT_SLOTS partial vectors from the fused GEMM epilogues
-            const int slots = (train == 2) ? TIC_BN_STAT_SLOTS : 1;
-            for (int k = 0; k < slots; ++k) {
-                s1 += sums[(long)k * 2 * C + c];
-                s2 += sums[(long)k * 2 * C + C + c];
-            }
-            const float mu = s1 / (float)M;
-            float var = s2 / (float)M - mu * mu;
+            const float mu = sums[c] / (float)M;
+            float var = sums[C + c] / (float)M - mu * mu;
             if (var < 0.f) var = 0.f;
             mean[c] = mu;
             rstd[c] = 1.0f / sqrtf(var + eps);

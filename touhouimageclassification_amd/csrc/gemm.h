@@ -38,8 +38,6 @@ struct GemmNtParams {
     const float* rowtab;     // [(P+1),N] fp32 (PATCH: position embeddings)
     int patches;             // P (PATCH)
     float* colsum;           // optional [N]: += column sums of the stored output (bias gradient of the consumer), BF16 / DGELU
-    float* colsumsq;         // optional [N] (EPI_BF16): += column sums of the SQUARED stored output -- with colsum, the BatchNorm batch statistics of a conv output
-    int stat_slots;          // > 1: colsum / colsumsq are [stat_slots][2N] partial vectors (BatchNorm statistics), slot = workgroup & (stat_slots-1)
     ConvGather cg;           // gemm_nt_kernel<EPI, true> only
     int nt;                  // 256x256 staged epilogue: bit 0 non-temporal output stores, bit 1 non-temporal operand loads
     int gm;                  // m-tiles per group of the XCD-local tile walk (tile_coords), 0 = 8
@@ -90,12 +88,8 @@ TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, EpiExtra e
     if (m >= p.M || n >= p.N) return f32x4{0.f, 0.f, 0.f, 0.f};   // ragged M; N not a multiple of the tile (conv channels 64, C*k*k ...)
     const size_t o = (size_t)m * p.N + n;
     if (EPI == TIC_EPI_BF16) {
-        const u32x2 u = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        *reinterpret_cast<u32x2*>(p.out + o) = u;
-        // the STORED (bf16) values: column sums of them are what a consumer of the tensor would compute
-        union { uint32_t i; float f; } a, b, c, d;
-        a.i = u[0] << 16; b.i = u[0] & 0xffff0000u; c.i = u[1] << 16; d.i = u[1] & 0xffff0000u;
-        return f32x4{a.f, b.f, c.f, d.f};
+        *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        return v;
     } else if (EPI == TIC_EPI_GELU) {
         float u[4], g[4];
 #pragma unroll
@@ -142,10 +136,9 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
     constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX || EPI == TIC_EPI_PATCH);
     constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
     EpiExtra ex[2][NG];
-    f32x4 cs[NG], cq[NG];
+    f32x4 cs[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) cs[g] = cq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool want_sq = (EPI == TIC_EPI_BF16) && p.colsumsq;   // kernel-argument condition: wave-uniform
+    for (int g = 0; g < NG; ++g) cs[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (HAS_EXTRA) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) ex[0][g] = epi_fetch<EPI>(p, row_of(0), col_of(g));
@@ -160,12 +153,10 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
         for (int g = 0; g < NG; ++g) {
             const f32x4 w4 = epi_store<EPI>(p, row_of(r), col_of(g), acc_of(r, g), ex[r & 1][g]);
             if (HAS_COLSUM) cs[g] += w4;
-            if (want_sq) cq[g] += w4 * w4;
         }
     }
     // fused bias gradient: this lane's rows are summed above; the 16 lanes that share (l>>4) hold the other rows of the
     // same 4 columns -> butterfly over lane bits 0..3, then one lane per column group adds to the global vector
-    const size_t slot_off = p.stat_slots > 1 ? (size_t)(TIC_BID_X & (p.stat_slots - 1)) * 2 * p.N : 0;
     if (HAS_COLSUM && p.colsum) {   // kernel-argument condition: wave-uniform
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -176,21 +167,7 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
                 v += shfl_xor(v, 2);
                 v += shfl_xor(v, 4);
                 v += shfl_xor(v, 8);
-                if ((lane_id() & 15) == 0 && col_of(g) + c < p.N) atomic_addf(p.colsum + slot_off + col_of(g) + c, v);
-            }
-        }
-    }
-    if (want_sq) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float v = cq[g][c];
-                v += shfl_xor(v, 1);
-                v += shfl_xor(v, 2);
-                v += shfl_xor(v, 4);
-                v += shfl_xor(v, 8);
-                if ((lane_id() & 15) == 0 && col_of(g) + c < p.N) atomic_addf(p.colsumsq + slot_off + col_of(g) + c, v);
+                if ((lane_id() & 15) == 0 && col_of(g) + c < p.N) atomic_addf(p.colsum + col_of(g) + c, v);
             }
         }
     }

@@ -41,7 +41,7 @@
 
 #define G256_BUF_BYTES 65536u   // A 32 KiB + B 32 KiB
 #define G256_LDS_BYTES (2u * G256_BUF_BYTES)
-#define G256_NT_LDS_BYTES (G256_LDS_BYTES + 16384u)   // + 2 x [8 waves][256] fp32 column-sum (and sum-of-squares) partials of the staged epilogue
+#define G256_NT_LDS_BYTES (G256_LDS_BYTES + 8192u)   // + [8 waves][256] fp32 column-sum partials of the staged epilogue
 
 TIC_DEV void g256_barrier() {
 #ifndef TIC_SIM
@@ -83,8 +83,7 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
     const int tid = TIC_TID, c16 = tid & 31, rsub = tid >> 5;
     const int n = n0 + c16 * 8;
     const uint32_t lds0 = (uint32_t)rsub * 512u + (uint32_t)(((c16 * 2) ^ (rsub << 2)) * 8);
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool want_sq = (EPI == TIC_EPI_BF16) && p.colsumsq;   // kernel-argument condition: block-uniform
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     u32x4 aux[2][PF];
     auto fetch = [&](int b) {
         if (HAS_AUX) {
@@ -110,13 +109,8 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
                 st_u4<NTS>(p.out + o, u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float lo = bf_lo(u[j]), hi = bf_hi(u[j]);
-                    cs[2 * j] += lo;
-                    cs[2 * j + 1] += hi;
-                    if (want_sq) {
-                        cq[2 * j] += lo * lo;
-                        cq[2 * j + 1] += hi * hi;
-                    }
+                    cs[2 * j] += bf_lo(u[j]);
+                    cs[2 * j + 1] += bf_hi(u[j]);
                 }
             } else if (EPI == TIC_EPI_GELU) {
                 u32x4 g;
@@ -154,27 +148,17 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
     // threads add one contiguous fp32 row to the global vector
     if (HAS_COLSUM && p.colsum) {   // kernel-argument condition: block-uniform
         const int l = tid & 63, w = tid >> 6;
-        const size_t slot_off = p.stat_slots > 1 ? (size_t)(TIC_BID_X & (p.stat_slots - 1)) * 2 * p.N : 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             cs[j] += shfl_xor(cs[j], 32);
             if (l < 32) lds_stf(G256_LDS_BYTES + (uint32_t)(w * 256 + c16 * 8 + j) * 4u, cs[j]);
-            if (want_sq) {
-                cq[j] += shfl_xor(cq[j], 32);
-                if (l < 32) lds_stf(G256_LDS_BYTES + 8192u + (uint32_t)(w * 256 + c16 * 8 + j) * 4u, cq[j]);
-            }
         }
         block_sync();
         if (tid < 256) {
             float t = 0.f;
 #pragma unroll
             for (int ww = 0; ww < 8; ++ww) t += lds_ldf(G256_LDS_BYTES + (uint32_t)(ww * 256 + tid) * 4u);
-            atomic_addf(p.colsum + slot_off + n0 + tid, t);
-        } else if (want_sq) {   // threads 256..511: the sums of squares
-            float t = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < 8; ++ww) t += lds_ldf(G256_LDS_BYTES + 8192u + (uint32_t)(ww * 256 + tid - 256) * 4u);
-            atomic_addf(p.colsumsq + slot_off + n0 + tid - 256, t);
+            atomic_addf(p.colsum + n0 + tid, t);
         }
     }
 }

@@ -112,19 +112,10 @@ extern "C" int tic_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
                                 const void* aux_bf16, const float* rowtab, int patches, tic_stream_t stream) {
     return tic_gemm_nt_bf16_ex(A, B, M, N, K, epilogue, bias, out_bf16, out2_bf16, out_f32, resid, aux_bf16, rowtab, patches, nullptr, stream);
 }
-static int gemm_nt_launch(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias, void* out_bf16, void* out2_bf16,
-                          float* out_f32, const float* resid, const void* aux_bf16, const float* rowtab, int patches, float* colsum,
-                          float* colsumsq, tic_stream_t stream);
 extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
                                    void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
                                    const void* aux_bf16, const float* rowtab, int patches, float* colsum, tic_stream_t stream) {
-    return gemm_nt_launch(A, B, M, N, K, epilogue, bias, out_bf16, out2_bf16, out_f32, resid, aux_bf16, rowtab, patches, colsum, nullptr, stream);
-}
-static int gemm_nt_launch(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias, void* out_bf16, void* out2_bf16,
-                          float* out_f32, const float* resid, const void* aux_bf16, const float* rowtab, int patches, float* colsum,
-                          float* colsumsq, tic_stream_t stream) {
     TIC_REQUIRE(A && B, "gemm_nt: null operand");
-    TIC_REQUIRE(!colsumsq || (colsum && epilogue == TIC_EPI_BF16), "gemm_nt: sums of squares come with colsum on EPI_BF16 only");
     TIC_REQUIRE(!colsum || epilogue == TIC_EPI_BF16 || epilogue == TIC_EPI_DGELU || epilogue == TIC_EPI_MULAUX,
                 "gemm_nt: colsum is available for EPI_BF16 / EPI_DGELU / EPI_MULAUX only");
     TIC_REQUIRE(M >= 1 && N >= 8 && K >= 64, "gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
@@ -140,8 +131,6 @@ static int gemm_nt_launch(const void* A, const void* B, int M, int N, int K, int
 
     p.out = (bf16_t*)out_bf16; p.out2 = (bf16_t*)out2_bf16; p.out_f32 = out_f32; p.resid = resid;
     p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches; p.colsum = colsum;
-    p.colsumsq = colsumsq;
-    p.stat_slots = colsumsq ? TIC_BN_STAT_SLOTS : 1;
     // big products go to the deep-pipelined 256x256 kernel (one block per CU), the rest to the 128x128 one
     const bool big = (N % 256 == 0) && (g_opt_gemm_tile == 256 || (g_opt_gemm_tile == 0 && (long)M * N >= (long)2048 * 1024));
     const int grid = big ? (int)(((M + 255) / 256) * (N / 256)) : (int)(tiles_m * ((N + 127) / 128));
@@ -503,14 +492,8 @@ extern "C" int tic_conv_weight_pack(const float* w_oihw, void* w16, int Co, int 
     TIC_LAUNCH(weight_ohwi_kernel, ew_grid((long)Co * g.Kp), 256, 0, stream, w_oihw, (bf16_t*)w16, Co, g, transposed);
     return tic_after_launch("conv_weight_pack");
 }
-// out[M,N] = A . B^T (bf16, no bias) and, fused into the epilogue, sums[0..N) += column sums of out, sums[N..2N) += column
-// sums of out^2: a convolution as a GEMM together with the BatchNorm batch statistics of its output
-extern "C" int tic_gemm_nt_stats_bf16(const void* A, const void* B, int M, int N, int K, void* out_bf16, float* sums2n, tic_stream_t stream) {
-    TIC_REQUIRE(sums2n, "gemm_nt_stats: null sums");
-    return gemm_nt_launch(A, B, M, N, K, TIC_EPI_BF16, nullptr, out_bf16, nullptr, nullptr, nullptr, nullptr, nullptr, 0, sums2n, sums2n + N, stream);
-}
 // implicit-GEMM convolution (3x3 and friends with Cin % 64 == 0): y[M = B*Ho*Wo, Cout] = gather(x) . Wpack^T
-extern "C" int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, float* stats2c, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+extern "C" int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                                   int stride, int pad, tic_stream_t stream) {
     TIC_REQUIRE(x_nhwc && w_pack && y && B >= 1, "conv_igemm_fwd: bad argument");
     TIC_REQUIRE(Cin % 64 == 0 && Cout % 8 == 0 && kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "conv_igemm_fwd: need Cin %% 64 == 0, Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
@@ -523,12 +506,6 @@ extern "C" int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* 
     GemmNtParams p;
     memset(&p, 0, sizeof(p));
     p.A = (const bf16_t*)x_nhwc; p.B = (const bf16_t*)w_pack; p.M = (int)M; p.N = Cout; p.K = K; p.out = (bf16_t*)y;
-    p.stat_slots = 1;
-    if (stats2c) {   // BatchNorm statistics of the output, fused: [TIC_BN_STAT_SLOTS][2 Cout] partial vectors
-        p.colsum = stats2c;
-        p.colsumsq = stats2c + Cout;
-        p.stat_slots = TIC_BN_STAT_SLOTS;
-    }
     p.cg.H = H; p.cg.W = W; p.cg.Cin = Cin; p.cg.Ho = Ho; p.cg.Wo = Wo; p.cg.KW = kw; p.cg.stride = stride; p.cg.pad = pad;
     const int grid = (int)(((M + 127) / 128) * ((Cout + 127) / 128));
     TIC_RT_MAX_LDS((gemm_nt_kernel<TIC_EPI_BF16, true>), GEMM_LDS_BYTES);
@@ -599,7 +576,7 @@ extern "C" int tic_batchnorm_fwd(const void* x, const float* gamma, const float*
                                  float eps, float momentum, int train, int relu, tic_stream_t stream) {
     TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && scratch2c && y, "batchnorm_fwd: null pointer");
     TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_fwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
-    if (train == 1) {   // train == 2: scratch2c already holds sum / sum of squares (fused into the producing GEMM)
+    if (train) {
         TIC_RT_MEMSET(scratch2c, 0, (size_t)2 * C * 4, stream);
         TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, scratch2c, M, C);
     }
