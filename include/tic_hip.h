@@ -101,6 +101,10 @@ int tic_attention_bwd(const void* qkv, const void* o, const float* lse, const vo
 /* + dbias (optional, fp32 [3D]) += column sums of dqkv (gradient of the fused q/k/v bias) */
 int tic_attention_bwd_ex(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias, int B,
                          int H, int N, float scale, tic_stream_t stream);
+/* same with a caller-owned fp32 scratch [B][3*H*64]: each (image, head) stores its 192 column sums there and a second tiny
+ * kernel adds the images into dbias -- no global atomics (they cost 25 % of the backward kernel at 5 312 workgroups) */
+int tic_attention_bwd_ws(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias, float* scratch_b3d, int B,
+                         int H, int N, float scale, tic_stream_t stream);
 
 /* pixel_values [B,C,img,img] fp32 -> patch matrix [B*(img/patch)^2, C*patch*patch] bf16 (HF:60,69) */
 int tic_patchify(const float* x, void* P_bf16, int B, int C, int img, int patch, tic_stream_t stream);

@@ -341,3 +341,9 @@ def check_fused_bias_gradients(env):
     dbias = torch.zeros(3 * Dm, device=dev)
     call("tic_attention_bwd_ex", ptr(qkv), ptr(o), ptr(lse), ptr(do), ptr(dqkv), ptr(dbias), B, H, N, 0.125, None)
     torch.testing.assert_close(dbias, dqkv.float().sum(0), atol=0.05, rtol=0.02)
+    # the atomics-free form: per-image sums in a caller-owned scratch, added up by a second kernel (+= into dbias)
+    dbias2, dqkv2 = torch.full((3 * Dm,), 0.5, device=dev), torch.empty_like(qkv)
+    scratch = torch.full((B, 3 * Dm), 9.0, device=dev)
+    call("tic_attention_bwd_ws", ptr(qkv), ptr(o), ptr(lse), ptr(do), ptr(dqkv2), ptr(dbias2), ptr(scratch), B, H, N, 0.125, None)
+    assert torch.equal(dqkv2, dqkv)
+    torch.testing.assert_close(dbias2, 0.5 + dbias, atol=1e-3, rtol=1e-4)

@@ -15,7 +15,7 @@ class TicLibraryError(RuntimeError):
 
 @functools.lru_cache(maxsize=1)
 def lib() -> ctypes.CDLL:
-    path = build.LIB
+    path = os.environ.get("TIC_HIP_LIB", build.LIB)   # TIC_HIP_LIB: A/B a previously built libtic_hip*.so (measurement only)
     if not os.path.exists(path):
         try:
             build.build_hip()

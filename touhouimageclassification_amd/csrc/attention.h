@@ -33,6 +33,7 @@ struct AttnParams {
     const bf16_t* d_o;   // [M, D]        (bwd)
     bf16_t* dqkv;        // [M, 3D]       (bwd out)
     float* dbias;        // [3D] optional (bwd): += column sums of dqkv = gradient of the fused q/k/v bias
+    float* dbias_part;   // [B][3D] optional (bwd): per-image column sums, PLAIN stores (no atomics); reduced by attn_dbias_reduce_kernel
     int B, H, N, D;      // D = H * 64
     float scale;
 };
@@ -347,6 +348,29 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                 }
             }
         block_sync();
-        if (tid < 3 * ATT_HD) atomic_addf(p.dbias + (tid >> 6) * D + h * ATT_HD + (tid & 63), lds_ldf(DBL + 4u * tid));
+        if (tid < 3 * ATT_HD) {
+            const float v = lds_ldf(DBL + 4u * tid);
+            const int col = (tid >> 6) * D + h * ATT_HD + (tid & 63);
+            // 5 312 workgroups x 192 atomics on 3 072 addresses cost ~25 % of this kernel: with a partial buffer each
+            // (image, head) stores its own 192 sums and a tiny second kernel adds the images up
+            if (p.dbias_part) p.dbias_part[(size_t)b * 3 * D + col] = v;
+            else atomic_addf(p.dbias + col, v);
+        }
     }
+}
+
+// dbias[c] += sum_b part[b][c]   (c < cols; one thread per column, coalesced across the block)
+__global__ void __launch_bounds__(256) attn_dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int B, int cols) {
+    const int c = TIC_BID_X * 256 + TIC_TID;
+    if (c >= cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < B; b += 4) {
+        s0 += part[(size_t)b * cols + c];
+        s1 += part[(size_t)(b + 1) * cols + c];
+        s2 += part[(size_t)(b + 2) * cols + c];
+        s3 += part[(size_t)(b + 3) * cols + c];
+    }
+    for (; b < B; ++b) s0 += part[(size_t)b * cols + c];
+    dbias[c] += (s0 + s1) + (s2 + s3);
 }
