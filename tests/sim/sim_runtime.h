@@ -330,6 +330,14 @@ TIC_DEV uint32_t uniform(uint32_t v) { return v; }
 TIC_DEV void atomic_addf(float* p, float v) { *p += v; }
 TIC_DEV float fast_exp2(float x) { return exp2f(x); }
 TIC_DEV float fast_rcp(float x) { return 1.0f / x; }
+TIC_DEV float row16_sum(float v) {
+    for (int m = 1; m < 16; m <<= 1) v += shfl_xor(v, m);
+    return v;
+}
+TIC_DEV float wave64_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    return v;
+}
 TIC_DEV uint32_t lds_base() { return 0u; }
 TIC_DEV bf16x4 lds_tr64_hidden(uint32_t addr, uint32_t imm) { return lds_tr64(addr + imm); }
 template <int N = 0> TIC_DEV void lds_wait(bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}

@@ -331,12 +331,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float a = bk[dt][r], b2 = bv[dt][r];
-#pragma unroll
-                for (int msk = 1; msk < 16; msk <<= 1) {
-                    a += shfl_xor(a, msk);
-                    b2 += shfl_xor(b2, msk);
-                }
+                const float a = row16_sum(bk[dt][r]), b2 = row16_sum(bv[dt][r]);   // DPP: no LDS round trips
                 if (li == 0) {
                     const uint32_t col = (uint32_t)(dt * 16 + 4 * g + r);
                     if (w < 8) {

@@ -162,11 +162,7 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float v = cs[g][c];
-                v += shfl_xor(v, 1);
-                v += shfl_xor(v, 2);
-                v += shfl_xor(v, 4);
-                v += shfl_xor(v, 8);
+                const float v = row16_sum(cs[g][c]);
                 if ((lane_id() & 15) == 0 && col_of(g) + c < p.N) atomic_addf(p.colsum + col_of(g) + c, v);
             }
         }

@@ -10,11 +10,7 @@
 #pragma once
 #include "tic_prims.h"
 
-TIC_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
-    return v;
-}
+TIC_DEV float wave_sum(float v) { return wave64_sum(v); }
 
 // NV = ceil(D / 256): float4 groups per lane.  in_stride: elements between consecutive rows of x.
 template <int NV, bool NT = false>

@@ -120,7 +120,29 @@ TIC_DEV f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 // ---- cross-lane ---------------------------------------------------------------------------------
-TIC_DEV float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+TIC_DEV float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }   // ds_bpermute_b32: LDS-path latency per step
+// DPP forms (one VALU instruction per step, no LDS round trip): a butterfly of shfl_xor is a serial chain of ~120-cycle
+// ds_bpermute round trips -- 32 of them per wave at the end of the attention backward cost 25 % of that kernel.
+template <int CTRL, int ROW_MASK = 0xF>
+TIC_DEV float dpp_mov(float v) {   // lanes the control does not reach read 0 (bound_ctrl)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+// sum over each 16-lane row, result in all 16 lanes: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+TIC_DEV float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+// sum over the 64-lane wave, wave-uniform result: rows by DPP, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3,
+// the total lands in lane 63
+TIC_DEV float wave64_sum(float v) {
+    v = row16_sum(v);
+    v += dpp_mov<0x142, 0xA>(v);
+    v += dpp_mov<0x143, 0xC>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 TIC_DEV int lane_id() { return threadIdx.x & 63; }
 TIC_DEV int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 TIC_DEV uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
