@@ -61,9 +61,8 @@ TIC_DEV uint32_t att_tr_off(uint32_t row, uint32_t col) {
     return row * 128u + (((col >> 3) ^ swz128(row)) * 16u) + (col & 4u) * 2u;
 }
 TIC_DEV bf16x8 cat4(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
-TIC_DEV bf16x8 pack8(f32x4 a, f32x4 b) {
-    return bf16x8{(short)f2bf(a[0]), (short)f2bf(a[1]), (short)f2bf(a[2]), (short)f2bf(a[3]),
-                  (short)f2bf(b[0]), (short)f2bf(b[1]), (short)f2bf(b[2]), (short)f2bf(b[3])};
+TIC_DEV bf16x8 pack8(f32x4 a, f32x4 b) {   // four v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(bf16x8, u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])});
 }
 
 // [row-major tile][kk <-> permuted row] transposed fragment for reduction block `blk32` (32 rows),
