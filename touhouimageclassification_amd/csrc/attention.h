@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
 }
 
 // LDS: Q | K | V | dO tiles, then lse[224] and delta[224] floats
-#define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4 + 3 * ATT_HD * 4)   // + per-block q/k/v bias-gradient sums
+#define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4 + 8 * 3 * ATT_HD * 4)   // + q/k/v bias-gradient sums: 8 wave slots x [3][64]
 
 // 16 waves: waves 0-7 run phase A (dK, dV), waves 8-15 run phase B (dQ) CONCURRENTLY -- both only read the LDS tiles and
 // write disjoint outputs, so every SIMD hosts two waves of each phase and their latencies overlap (the 13 key tiles /
@@ -199,7 +199,6 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
             lds_stf(DEL + 4u * row, dl);
         }
     }
-    if (tid < 3 * ATT_HD) lds_stf(DBL + 4u * tid, 0.f);
     wait_vmcnt0();
     block_sync();
 
@@ -323,7 +322,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                 *reinterpret_cast<u32x2*>(qrow + dt * 16) = u32x2{pack2bf(dqa[dt][0], dqa[dt][1]), pack2bf(dqa[dt][2], dqa[dt][3])};
         }
     }
-    // q/k/v bias gradient: lanes (16 rows) -> wave (butterfly) -> workgroup (LDS adds) -> ONE global atomic per column.
+    // q/k/v bias gradient: lanes (16 rows, DPP) -> wave slot in LDS (plain stores) -> 192 threads add the 8 slots -> ONE value per column.
     // Adding per tile straight to global memory put 2 656 workgroups on the same 3D addresses (14x slower atomics).
     if (p.dbias) {   // kernel argument: uniform
 #pragma unroll
@@ -331,19 +330,21 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float a = row16_sum(bk[dt][r]), b2 = row16_sum(bv[dt][r]);   // DPP: no LDS round trips
-                if (li == 0) {
-                    const uint32_t col = (uint32_t)(dt * 16 + 4 * g + r);
+                if (li == 0) {   // plain stores into this wave's slot (phase-A wave w and phase-B wave w + 8 share slot w: disjoint columns)
+                    const uint32_t col = (uint32_t)(dt * 16 + 4 * g + r), slot = DBL + (uint32_t)(w & 7) * (3u * ATT_HD * 4u);
                     if (w < 8) {
-                        lds_addf(DBL + 4u * (64u + col), a);
-                        lds_addf(DBL + 4u * (128u + col), b2);
+                        lds_stf(slot + 4u * (64u + col), a);
+                        lds_stf(slot + 4u * (128u + col), b2);
                     } else {
-                        lds_addf(DBL + 4u * col, a);
+                        lds_stf(slot + 4u * col, a);
                     }
                 }
             }
         block_sync();
         if (tid < 3 * ATT_HD) {
-            const float v = lds_ldf(DBL + 4u * tid);
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += lds_ldf(DBL + (uint32_t)k * (3u * ATT_HD * 4u) + 4u * tid);
             const int col = (tid >> 6) * D + h * ATT_HD + (tid & 63);
             // 5 312 workgroups x 192 atomics on 3 072 addresses cost ~25 % of this kernel: with a partial buffer each
             // (image, head) stores its own 192 sums and a tiny second kernel adds the images up
