@@ -103,8 +103,10 @@ int tic_attention_bwd_ex(const void* qkv, const void* o, const float* lse, const
                          int H, int N, float scale, tic_stream_t stream);
 /* same with a caller-owned fp32 scratch [B][3*H*64]: each (image, head) stores its 192 column sums there and a second tiny
  * kernel adds the images into dbias -- no global atomics (they cost 25 % of the backward kernel at 5 312 workgroups) */
-int tic_attention_bwd_ws(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias, float* scratch_b3d, int B,
-                         int H, int N, float scale, tic_stream_t stream);
+int tic_attention_bwd_ws(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias, float* scratch_b3d,
+                         int skip_v_bias, int B, int H, int N, float scale, tic_stream_t stream);
+/* skip_v_bias != 0 leaves dbias[2D..3D) alone: the gradient of the v bias equals the column sums of d_o (dV = P^T dO and the rows of
+ * P sum to 1), which the GEMM producing d_o adds for free through its colsum epilogue */
 
 /* pixel_values [B,C,img,img] fp32 -> patch matrix [B*(img/patch)^2, C*patch*patch] bf16 (HF:60,69) */
 int tic_patchify(const float* x, void* P_bf16, int B, int C, int img, int patch, tic_stream_t stream);

@@ -344,6 +344,12 @@ def check_fused_bias_gradients(env):
     # the atomics-free form: per-image sums in a caller-owned scratch, added up by a second kernel (+= into dbias)
     dbias2, dqkv2 = torch.full((3 * Dm,), 0.5, device=dev), torch.empty_like(qkv)
     scratch = torch.full((B, 3 * Dm), 9.0, device=dev)
-    call("tic_attention_bwd_ws", ptr(qkv), ptr(o), ptr(lse), ptr(do), ptr(dqkv2), ptr(dbias2), ptr(scratch), B, H, N, 0.125, None)
+    call("tic_attention_bwd_ws", ptr(qkv), ptr(o), ptr(lse), ptr(do), ptr(dqkv2), ptr(dbias2), ptr(scratch), 0, B, H, N, 0.125, None)
     assert torch.equal(dqkv2, dqkv)
     torch.testing.assert_close(dbias2, 0.5 + dbias, atol=1e-3, rtol=1e-4)
+    # skip_v_bias: the v third is left alone; it equals the column sums of dO (rows of P sum to 1) up to the bf16 rounding of P
+    dbias3 = torch.full((3 * Dm,), 0.25, device=dev)
+    call("tic_attention_bwd_ws", ptr(qkv), ptr(o), ptr(lse), ptr(do), ptr(dqkv2), ptr(dbias3), ptr(scratch), 1, B, H, N, 0.125, None)
+    torch.testing.assert_close(dbias3[:2 * Dm], 0.25 + dbias[:2 * Dm], atol=1e-3, rtol=1e-4)
+    assert torch.equal(dbias3[2 * Dm:], torch.full((Dm,), 0.25, device=dev))
+    torch.testing.assert_close(do.float().sum(0), dbias[2 * Dm:], atol=0.02 * float(do.float().abs().sum(0).max()) + 0.05, rtol=0.02)

@@ -47,7 +47,7 @@ SIGNATURES = {
     "tic_gemm_nt_bf16_ex": ([P, P, I, I, I, I, P, P, P, P, P, P, P, I, P, P], I),
     "tic_layernorm_bwd_ex": ([P, P, L, P, P, P, P, P, P, P, P, P, I, I, P], I),
     "tic_attention_bwd_ex": ([P, P, P, P, P, P, I, I, I, F, P], I),
-    "tic_attention_bwd_ws": ([P, P, P, P, P, P, P, I, I, I, F, P], I),
+    "tic_attention_bwd_ws": ([P, P, P, P, P, P, P, I, I, I, I, F, P], I),
     "tic_gemm_tn_bf16": ([P, P, P, I, I, I, P], I),
     "tic_gemm_tn_group_bf16": ([I, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I), I, P], I),
     "tic_layernorm_fwd": ([P, L, P, P, P, P, P, I, I, F, P], I),

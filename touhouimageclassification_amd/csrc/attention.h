@@ -33,6 +33,7 @@ struct AttnParams {
     const bf16_t* d_o;   // [M, D]        (bwd)
     bf16_t* dqkv;        // [M, 3D]       (bwd out)
     float* dbias;        // [3D] optional (bwd): += column sums of dqkv = gradient of the fused q/k/v bias
+    int skip_v_bias;     // bwd: the v third of dbias is produced elsewhere (= column sums of dO, because the rows of P sum to 1)
     float* dbias_part;   // [B][3D] optional (bwd): per-image column sums, PLAIN stores (no atomics); reduced by attn_dbias_reduce_kernel
     int B, H, N, D;      // D = H * 64
     float scale;
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float a = row16_sum(bk[dt][r]), b2 = row16_sum(bv[dt][r]);   // DPP: no LDS round trips
+                const float a = row16_sum(bk[dt][r]), b2 = p.skip_v_bias ? 0.f : row16_sum(bv[dt][r]);   // DPP: no LDS round trips
                 if (li == 0) {   // plain stores into this wave's slot (phase-A wave w and phase-B wave w + 8 share slot w: disjoint columns)
                     const uint32_t col = (uint32_t)(dt * 16 + 4 * g + r), slot = DBL + (uint32_t)(w & 7) * (3u * ATT_HD * 4u);
                     if (w < 8) {
@@ -348,16 +349,18 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
             const int col = (tid >> 6) * D + h * ATT_HD + (tid & 63);
             // 5 312 workgroups x 192 atomics on 3 072 addresses cost ~25 % of this kernel: with a partial buffer each
             // (image, head) stores its own 192 sums and a tiny second kernel adds the images up
-            if (p.dbias_part) p.dbias_part[(size_t)b * 3 * D + col] = v;
+            if (p.skip_v_bias && tid >= 2 * ATT_HD) {
+                // nothing: dbias_v comes from the column sums of dO (fused into the GEMM that produced dO)
+            } else if (p.dbias_part) p.dbias_part[(size_t)b * 3 * D + col] = v;
             else atomic_addf(p.dbias + col, v);
         }
     }
 }
 
 // dbias[c] += sum_b part[b][c]   (c < cols; one thread per column, coalesced across the block)
-__global__ void __launch_bounds__(256) attn_dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int B, int cols) {
+__global__ void __launch_bounds__(256) attn_dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int B, int cols, int used) {
     const int c = TIC_BID_X * 256 + TIC_TID;
-    if (c >= cols) return;
+    if (c >= used) return;   // rows of `part` have stride `cols`, the first `used` columns are summed
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = 0;
     for (; b + 3 < B; b += 4) {

@@ -350,19 +350,21 @@ extern "C" int tic_attention_bwd(const void* qkv, const void* o, const float* ls
     return tic_attention_bwd_ex(qkv, o, lse, d_o, dqkv, nullptr, B, H, N, scale, stream);
 }
 static int attention_bwd_launch(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias, float* dbias_part,
-                                int B, int H, int N, float scale, tic_stream_t stream);
+                                int skip_v_bias, int B, int H, int N, float scale, tic_stream_t stream);
 extern "C" int tic_attention_bwd_ex(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias,
                                     int B, int H, int N, float scale, tic_stream_t stream) {
-    return attention_bwd_launch(qkv, o, lse, d_o, dqkv, dbias, nullptr, B, H, N, scale, stream);
+    return attention_bwd_launch(qkv, o, lse, d_o, dqkv, dbias, nullptr, 0, B, H, N, scale, stream);
 }
 // same, with a caller-owned fp32 scratch [B][3*H*64]: the q/k/v bias gradient is formed without global atomics
+// skip_v_bias != 0: the v third of dbias is left untouched -- it equals the column sums of dO (the rows of P sum to 1), which the
+// GEMM that produced dO can add for free (tic_gemm_nt_bf16_ex colsum)
 extern "C" int tic_attention_bwd_ws(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias, float* scratch_b3d,
-                                    int B, int H, int N, float scale, tic_stream_t stream) {
+                                    int skip_v_bias, int B, int H, int N, float scale, tic_stream_t stream) {
     TIC_REQUIRE(!scratch_b3d || dbias, "attention_bwd_ws: scratch without dbias");
-    return attention_bwd_launch(qkv, o, lse, d_o, dqkv, dbias, scratch_b3d, B, H, N, scale, stream);
+    return attention_bwd_launch(qkv, o, lse, d_o, dqkv, dbias, scratch_b3d, skip_v_bias, B, H, N, scale, stream);
 }
 static int attention_bwd_launch(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, float* dbias, float* dbias_part,
-                                int B, int H, int N, float scale, tic_stream_t stream) {
+                                int skip_v_bias, int B, int H, int N, float scale, tic_stream_t stream) {
     TIC_REQUIRE(qkv && o && lse && d_o && dqkv, "attention_bwd: null pointer");
     TIC_REQUIRE(B >= 1 && H >= 1 && N >= 1 && N <= 208, "attention_bwd: need 1 <= N <= 208 (N=%d)", N);
     TIC_REQUIRE((double)B * N * 3 * H * 64 * 2 < 4294967296.0, "attention_bwd: qkv exceeds the 4 GiB buffer-resource range");
@@ -371,9 +373,12 @@ static int attention_bwd_launch(const void* qkv, const void* o, const float* lse
     p.qkv = (const bf16_t*)qkv; p.o = (bf16_t*)o; p.lse = (float*)lse; p.d_o = (const bf16_t*)d_o; p.dqkv = (bf16_t*)dqkv; p.dbias = dbias;
     p.B = B; p.H = H; p.N = N; p.D = H * 64; p.scale = scale;
     p.dbias_part = dbias ? dbias_part : nullptr;
+    p.skip_v_bias = (dbias && skip_v_bias) ? 1 : 0;
     TIC_RT_MAX_LDS(attn_bwd_kernel, ATT_BWD_LDS);
     TIC_LAUNCH(attn_bwd_kernel, B * H, 1024, ATT_BWD_LDS, stream, p);
-    if (p.dbias_part) TIC_LAUNCH(attn_dbias_reduce_kernel, (3 * H * 64 + 255) / 256, 256, 0, stream, (const float*)dbias_part, dbias, B, 3 * H * 64);
+    if (p.dbias_part)   // the scratch rows keep the [3D] stride; with skip_v_bias only the q and k thirds are summed
+        TIC_LAUNCH(attn_dbias_reduce_kernel, ((p.skip_v_bias ? 2 : 3) * H * 64 + 255) / 256, 256, 0, stream, (const float*)dbias_part, dbias, B, 3 * H * 64,
+                   (p.skip_v_bias ? 2 : 3) * H * 64);
     return tic_after_launch("attention_bwd");
 }
 
@@ -844,9 +849,10 @@ extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stre
     TIC_TRY(tic_gemm_nt_bf16(du, lt + y.t_w1, M, D, F, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
     TIC_TRY(tic_layernorm_bwd_ex(da, (float*)(a + y.hmid), D, lp + y.ln2_g, (float*)(a + y.mean2), (float*)(a + y.rstd2), dh, dh, dhb2, lg + y.ln2_g,
                                  lg + y.ln2_b, lg + y.bo, M, D, s));
-    TIC_TRY(tic_gemm_nt_bf16(dhb2, lt + y.t_wo, M, D, D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
+    // dO = dh . Wo (no bias); its column sums ARE the gradient of the v bias (dV = P^T dO and the rows of P sum to 1)
+    TIC_TRY(tic_gemm_nt_bf16_ex(dhb2, lt + y.t_wo, M, D, D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, lg + y.bqkv + 2 * D, s));
     // scratch for the per-image bias-gradient sums: the saved gelu' buffer of this layer, dead since the MULAUX GEMM above
-    TIC_TRY(tic_attention_bwd_ws(a + y.qkv, a + y.o, (float*)(a + y.lse), da, dqkv, lg + y.bqkv, (float*)(a + y.u), B, (int)c.H, N, 0.125f, s));
+    TIC_TRY(tic_attention_bwd_ws(a + y.qkv, a + y.o, (float*)(a + y.lse), da, dqkv, lg + y.bqkv, (float*)(a + y.u), 1, B, (int)c.H, N, 0.125f, s));
     TIC_TRY(tic_gemm_nt_bf16(dqkv, lt + y.t_wqkv, M, D, 3 * D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
     {
         const void* gA[4] = {dhb, du, dhb2, dqkv};
