@@ -851,8 +851,10 @@ extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stre
                                  lg + y.ln2_b, lg + y.bo, M, D, s));
     // dO = dh . Wo (no bias); its column sums ARE the gradient of the v bias (dV = P^T dO and the rows of P sum to 1)
     TIC_TRY(tic_gemm_nt_bf16_ex(dhb2, lt + y.t_wo, M, D, D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, lg + y.bqkv + 2 * D, s));
-    // scratch for the per-image bias-gradient sums: the saved gelu' buffer of this layer, dead since the MULAUX GEMM above
-    TIC_TRY(tic_attention_bwd_ws(a + y.qkv, a + y.o, (float*)(a + y.lse), da, dqkv, lg + y.bqkv, (float*)(a + y.u), 1, B, (int)c.H, N, 0.125f, s));
+    // scratch for the per-image bias-gradient sums: the saved gelu' buffer of this layer ([M, F] bf16), dead since the MULAUX GEMM
+    // above -- when it is large enough for [B][3D] floats (always at 197 tokens; not for a 5-token test model: atomics then)
+    float* part = ((size_t)M * F * 2 >= (size_t)B * 3 * D * 4) ? (float*)(a + y.u) : nullptr;
+    TIC_TRY(tic_attention_bwd_ws(a + y.qkv, a + y.o, (float*)(a + y.lse), da, dqkv, lg + y.bqkv, part, 1, B, (int)c.H, N, 0.125f, s));
     TIC_TRY(tic_gemm_nt_bf16(dqkv, lt + y.t_wqkv, M, D, 3 * D, TIC_EPI_BF16, nullptr, da, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s));
     {
         const void* gA[4] = {dhb, du, dhb2, dqkv};
