@@ -376,9 +376,12 @@ static int attention_bwd_launch(const void* qkv, const void* o, const float* lse
     p.skip_v_bias = (dbias && skip_v_bias) ? 1 : 0;
     TIC_RT_MAX_LDS(attn_bwd_kernel, ATT_BWD_LDS);
     TIC_LAUNCH(attn_bwd_kernel, B * H, 1024, ATT_BWD_LDS, stream, p);
-    if (p.dbias_part)   // the scratch rows keep the [3D] stride; with skip_v_bias only the q and k thirds are summed
-        TIC_LAUNCH(attn_dbias_reduce_kernel, ((p.skip_v_bias ? 2 : 3) * H * 64 + 255) / 256, 256, 0, stream, (const float*)dbias_part, dbias, B, 3 * H * 64,
-                   (p.skip_v_bias ? 2 : 3) * H * 64);
+    if (p.dbias_part) {   // the scratch rows keep the [3D] stride; with skip_v_bias only the q and k thirds are summed
+        const int used = (p.skip_v_bias ? 2 : 3) * H * 64;
+        int splits = (B + 3) / 4;
+        if (splits > 16) splits = 16;
+        TIC_LAUNCH(attn_dbias_reduce_kernel, dim3((used + 63) / 64, splits), 256, 1024, stream, (const float*)dbias_part, dbias, B, 3 * H * 64, used);
+    }
     return tic_after_launch("attention_bwd");
 }
 
