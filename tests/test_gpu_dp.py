@@ -51,3 +51,58 @@ def test_single_rank_rccl_bucket_path_is_transparent():
         assert (results[0][0] - results[1][0]).abs().max().item() < 5e-4
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # two ranks on ONE GPU: RCCL refuses that, gloo moves CUDA tensors
+    from touhouimageclassification_amd.ViT.model import ViT
+    from touhouimageclassification_amd.dist import BucketedGradSync
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from touhouimageclassification_amd.step import fused_train_step
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(100 + rank)   # replicas start different on purpose
+    m = ViT(10, pretrained=False, model_name="tiny").to(dev)
+    sync = BucketedGradSync(m)
+    assert sync.active and sync.comm_stream is not None
+    sync.broadcast_parameters()
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=0.01)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4 * world, 3, 224, 224, generator=g)
+    y = torch.randint(0, 10, (4 * world,), generator=g)
+    xs, ys = x[4 * rank:4 * rank + 4].to(dev), y[4 * rank:4 * rank + 4].to(dev)
+    losses = []
+    for _ in range(3):
+        loss, _ = fused_train_step(m, opt, xs, ys, sync)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    torch.save({"params": m._engine.params.cpu(), "grads": m._engine.grads.cpu(), "losses": losses}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_stay_identical_and_match_global_batch(tmp_path):
+    """the CUDA data-parallel path with TWO real ranks (both on this GPU, gloo transport): side-stream all-reduce per bucket,
+    optimizer behind it, three steps -- replicas bit-identical, first-step gradient = single-process gradient of the global batch"""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.start_processes(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["params"], r1["params"]) and torch.equal(r0["grads"], r1["grads"])
+    from touhouimageclassification_amd.ViT.model import ViT
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from touhouimageclassification_amd.step import fused_train_step
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(100)
+    m = ViT(10, pretrained=False, model_name="tiny").to(dev)
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=0.01)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 3, 224, 224, generator=g).to(dev)
+    y = torch.randint(0, 10, (8,), generator=g).to(dev)
+    losses = [float(fused_train_step(m, opt, x, y, None)[0]) for _ in range(3)]
+    assert abs(0.5 * (r0["losses"][0] + r1["losses"][0]) - losses[0]) < 2e-3
+    for a, b in zip([0.5 * (p + q) for p, q in zip(r0["losses"], r1["losses"])], losses):
+        assert abs(a - b) < 0.08 * max(b, 0.2), (r0["losses"], r1["losses"], losses)
