@@ -51,7 +51,7 @@ TIC_DEV void att_stage_tile(tic_rsrc_t r, uint32_t tile_off, long row0, int N, i
         if (piece >= 28) break;   // wave-uniform
         const int row = piece * 8 + (l >> 3);
         const uint32_t voff = (row < N) ? (uint32_t)((((size_t)(row0 + row)) * ld + col0 + slot_log * 8) * 2) : 0xFFFFFFF0u;
-        glds16(r, tile_off + (uint32_t)piece * 1024u, voff, 0);
+        glds16_nt(r, tile_off + (uint32_t)piece * 1024u, voff, 0);
     }
 }
 
