@@ -1,15 +1,23 @@
-"""Global constants of the reference (TIC/utils/parameter.py:1-16), unchanged values."""
-NUM_CLASSES = 120
-IMAGE_SIZE = (256, 256)
-VIT_IMAGE_SIZE = (224, 224)
-DATA_DIR = "data/train"
-UNFILTERED_DATA_DIR = "data/train"
-FILTERED_DATA_DIR = "data/filtered"
-TEST_DIR = "data/test"
+"""Project-wide defaults shared by the harnesses (values of TIC/utils/parameter.py:1-16; names kept for drop-in imports)."""
+from typing import Tuple
+
+NUM_CLASSES = 120                      # dataset categories
+
+# image geometry: dataset thumbnails are 256 x 256, every ViT variant is fed 224 x 224
+IMAGE_SIZE: Tuple[int, int] = (256, 256)
+VIT_IMAGE_SIZE: Tuple[int, int] = (224, 224)
+
+# directory layout relative to the working directory
+_DATA_ROOT = "data"
+DATA_DIR = f"{_DATA_ROOT}/train"
+UNFILTERED_DATA_DIR = DATA_DIR
+FILTERED_DATA_DIR = f"{_DATA_ROOT}/filtered"
+TEST_DIR = f"{_DATA_ROOT}/test"
 CHECKPOINT_DIR = "checkpoint"
 LOG_DIR = "log"
 
 
-def get_image_size(model_name: str):
-    """ViT variants take 224x224, everything else the dataset's 256x256 thumbnails (parameter.py:12-16)."""
-    return VIT_IMAGE_SIZE if "vit" in model_name.lower() else IMAGE_SIZE
+def get_image_size(model_name: str) -> Tuple[int, int]:
+    """input resolution for a model name: ViT variants 224 x 224, everything else the thumbnail size (parameter.py:12-16)"""
+    is_vit = "vit" in model_name.lower()
+    return VIT_IMAGE_SIZE if is_vit else IMAGE_SIZE
