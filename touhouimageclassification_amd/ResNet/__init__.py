@@ -1,0 +1,1 @@
+"""ResNet path: ``model.resnet18 .. resnet152`` over the HIP conv / BatchNorm kernels, ``train`` (SGD harness)."""
