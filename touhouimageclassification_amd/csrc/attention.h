@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
             lds_stf(DEL + 4u * row, dl);
         }
     }
+    for (int i = tid; i < 8 * 3 * ATT_HD; i += 1024) lds_stf(DBL + 4u * (uint32_t)i, 0.f);
     wait_vmcnt0();
     block_sync();
 
@@ -208,12 +209,22 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     const int n16 = (N + 15) >> 4, n32 = (N + 31) >> 5;   // 13 / 7 at N = 197: tiles / tile pairs that hold real tokens
 
     // ---------------- phase A: dK, dV (key on the lane) -- waves 0..7 ----------------
-    f32x4 bk[4], bv[4];   // per-lane bias-gradient partials summed over this wave's tiles: (dk, dv) in phase A, (dq, -) in phase B
+    // q/k/v bias gradient = column sums of dq / dk / dv.  Every finished tile is reduced at once: 16-lane rows by DPP, then the
+    // wave adds into ITS OWN LDS slot (lane 0 of each row, read-modify-write, no atomics: phase-A wave w and phase-B wave
+    // w + 8 share slot w on disjoint columns).  Carrying per-lane partial sums across the tiles cost 32 VGPRs kernel-wide.
+    const uint32_t slot = DBL + (uint32_t)(w & 7) * (3u * ATT_HD * 4u);
+    auto reduce_cols = [&](const f32x4 (&part)[4], uint32_t col0) {
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        bk[dt] = f32x4{0, 0, 0, 0};
-        bv[dt] = f32x4{0, 0, 0, 0};
-    }
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = row16_sum(part[dt][r]);
+                if (li == 0) {
+                    const uint32_t addr = slot + 4u * (col0 + (uint32_t)(dt * 16 + 4 * g + r));
+                    lds_stf(addr, lds_ldf(addr) + a);
+                }
+            }
+    };
     if (w < 8)
     for (int kt = w; kt < n16; kt += 8) {
         const int key = kt * 16 + li;
@@ -260,10 +271,9 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                 dka[dt] = mfma16(att_tr_frag(QT, qp, dt, l), fds, dka[dt]);    // dK^T[d][key]
             }
         }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {   // padded keys contribute exact zeros (p = 0)
-            bk[dt] += dka[dt];
-            bv[dt] += dva[dt];
+        if (p.dbias) {   // kernel argument: uniform.  padded keys contribute exact zeros (p = 0)
+            reduce_cols(dka, 64u);
+            if (!p.skip_v_bias) reduce_cols(dva, 128u);
         }
         if (key_ok) {
             bf16_t* krow = p.dqkv + (size_t)(row0 + key) * ld + D + h * ATT_HD + 4 * g;
@@ -314,8 +324,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) dqa[dt] = mfma16(att_tr_frag(KT, kp, dt, l), fds, dqa[dt]);   // dQ^T[d][q]
         }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) bk[dt] += dqa[dt];
+        if (p.dbias) reduce_cols(dqa, 0u);
         if (q < N) {
             bf16_t* qrow = p.dqkv + (size_t)(row0 + q) * ld + h * ATT_HD + 4 * g;
 #pragma unroll
@@ -323,24 +332,8 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                 *reinterpret_cast<u32x2*>(qrow + dt * 16) = u32x2{pack2bf(dqa[dt][0], dqa[dt][1]), pack2bf(dqa[dt][2], dqa[dt][3])};
         }
     }
-    // q/k/v bias gradient: lanes (16 rows, DPP) -> wave slot in LDS (plain stores) -> 192 threads add the 8 slots -> ONE value per column.
-    // Adding per tile straight to global memory put 2 656 workgroups on the same 3D addresses (14x slower atomics).
+    // the 8 wave slots are added up by 192 threads -> ONE value per column and workgroup
     if (p.dbias) {   // kernel argument: uniform
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = row16_sum(bk[dt][r]), b2 = p.skip_v_bias ? 0.f : row16_sum(bv[dt][r]);   // DPP: no LDS round trips
-                if (li == 0) {   // plain stores into this wave's slot (phase-A wave w and phase-B wave w + 8 share slot w: disjoint columns)
-                    const uint32_t col = (uint32_t)(dt * 16 + 4 * g + r), slot = DBL + (uint32_t)(w & 7) * (3u * ATT_HD * 4u);
-                    if (w < 8) {
-                        lds_stf(slot + 4u * (64u + col), a);
-                        lds_stf(slot + 4u * (128u + col), b2);
-                    } else {
-                        lds_stf(slot + 4u * col, a);
-                    }
-                }
-            }
         block_sync();
         if (tid < 3 * ATT_HD) {
             float v = 0.f;
