@@ -278,7 +278,9 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
             return tic_after_launch("gemm_tn_group(dbg)");
         }
         TIC_RT_MAX_LDS(gemm_tn256_kernel<0>, G256_LDS_BYTES);
+        TIC_RT_TIMER_MARK(0, stream);
         TIC_LAUNCH(gemm_tn256_kernel<0>, t, 512, G256_LDS_BYTES, stream, gp);
+        TIC_RT_TIMER_MARK(1, stream);
         return tic_after_launch("gemm_tn_group");
     }
     for (int g = 0; g < nprob; ++g) TIC_TRY(tic_gemm_tn_bf16(A[g], B[g], C[g], M, N[g], K[g], stream));
