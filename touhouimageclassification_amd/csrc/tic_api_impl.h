@@ -49,6 +49,7 @@ static int g_opt_nt = 13;         // non-temporal loads / stores for once-touche
                                   // 2 AdamW (no effect: off), 4 staged GEMM epilogue stores (-0.8 %), 8 its residual / derivative operand loads (-0.1 %)
 static int g_opt_ln_blocks = 4096;   // grid cap of the LayerNorm kernels (4 rows per block per pass)
 static int g_opt_gemm_gm = 8;
+static int g_opt_tn_main_bias = 0;   // extra M steps given to the 'main' workgroups of the phase-aligned stream-K split (tail ones pay 3 prologues / epilogues)
 static int g_opt_gemm_dbg = 0;
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
@@ -56,6 +57,10 @@ static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the til
 extern "C" int tic_set_option(const char* name, int value) {
     if (name && !strcmp(name, "ln_blocks") && value >= 64 && value <= 65536) {
         g_opt_ln_blocks = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "tn_main_bias") && value >= 0 && value <= 64) {
+        g_opt_tn_main_bias = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "gemm_gm") && value >= 1 && value <= 256) {
@@ -254,7 +259,7 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
                 if (tails > 0 && tp % tails == 0) {
                     tpx = tp;
                     tail_each = tp / tails;
-                    s_main = (int)((long)nsteps * tail_each / (tail_each + 1));   // main: s_main steps; tail: tail_each x (S - s_main)
+                    s_main = (int)((long)nsteps * tail_each / (tail_each + 1)) + g_opt_tn_main_bias;   // main: s_main steps; tail: tail_each x (S - s_main)
                     if (s_main < 1 || s_main >= nsteps) s_main = 0;
                 }
             }
