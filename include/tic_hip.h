@@ -44,6 +44,8 @@ int tic_set_option(const char* name, int value);
 /* Live timing of the step's dominant kernel (the grouped dW launch of tic_gemm_tn_group_bf16 / tic_vit_backward_layer): while
  * enabled, HIP events are recorded on the launch stream around every such launch (up to 8192); read() waits for them and
  * returns how many launches were timed and their summed duration.  bench.py's roofline.achieved comes from this. */
+/* measurement only (tools/hbm_probe.py): streaming read (or copy, dst != NULL) of n floats; mode bit 0 = non-temporal accesses */
+int tic_probe_stream(const float* src, float* dst, float* sink, long n, int blocks, int mode, tic_stream_t stream);
 int tic_kernel_timer_enable(int on);
 int tic_kernel_timer_read(int* launches, float* total_ms);
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "tic_version": ([], I),
     "tic_last_error_string": ([], C.c_char_p),
     "tic_set_option": ([C.c_char_p, I], I),
+    "tic_probe_stream": ([P, P, P, C.c_long, I, I, P], I),
     "tic_kernel_timer_enable": ([I], I),
     "tic_kernel_timer_read": ([P, P], I),
     "tic_gemm_nt_bf16": ([P, P, I, I, I, I, P, P, P, P, P, P, P, I, P], I),

@@ -206,3 +206,15 @@ __global__ void __launch_bounds__(256) xent_kernel(const float* __restrict__ log
             dlogits[(long)b * C + c] = gscale * (__expf(z[c] - lz) * ts - t) * invB;
         }
 }
+
+// measurement only (tools/hbm_probe.py): streaming read of n4 float4 (mode bit 0: non-temporal loads), optional copy to dst
+template <bool NT>
+__global__ void __launch_bounds__(256) probe_stream_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ sink, long n4) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < n4; i += (long)TIC_NBLK_X * 256) {
+        const f32x4 v = ld_f4<NT>(src + i * 4);
+        if (dst) st_f4<NT>(dst + i * 4, v);
+        else acc += v;
+    }
+    if (!dst && acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) sink[0] = 1.f;   // keeps the loads alive
+}

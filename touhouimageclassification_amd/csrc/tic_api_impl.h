@@ -456,6 +456,13 @@ extern "C" int tic_adamw(float* p, const float* g, float* m, float* v, void* w16
         TIC_LAUNCH(adamw_kernel<false>, ew_grid(n / 4), 256, 0, stream, p, g, m, v, (bf16_t*)w16, n / 4, lr, beta1, beta2, eps, weight_decay, inv_bc1, inv_sqrt_bc2);
     return tic_after_launch("adamw");
 }
+// measurement only: stream n floats (n % 4 == 0) from src (and to dst when given) with `blocks` workgroups; mode bit 0 = non-temporal
+extern "C" int tic_probe_stream(const float* src, float* dst, float* sink, long n, int blocks, int mode, tic_stream_t stream) {
+    TIC_REQUIRE(src && sink && n >= 4 && n % 4 == 0 && blocks >= 1, "probe_stream: bad argument");
+    if (mode & 1) TIC_LAUNCH(probe_stream_kernel<true>, blocks, 256, 0, stream, src, dst, sink, n / 4);
+    else TIC_LAUNCH(probe_stream_kernel<false>, blocks, 256, 0, stream, src, dst, sink, n / 4);
+    return tic_after_launch("probe_stream");
+}
 extern "C" int tic_head_fwd(const void* z_bf16, const float* W, const float* bias, float* logits, int B, int C, int D,
                             tic_stream_t stream) {
     TIC_REQUIRE(z_bf16 && W && bias && logits && B >= 1 && C >= 1 && D % 4 == 0, "head_fwd: bad argument");
