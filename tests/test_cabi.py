@@ -38,6 +38,17 @@ def test_argument_validation_without_gpu():
     assert lay.n_params >= 303_424_632 and lay.n_params - 303_424_632 < 4096   # ViT-L/16 C=120 (+ padding)
     d.D = 1000
     assert lib.tic_vit_layout(ctypes.byref(d), ctypes.byref(lay)) == -1
+    # newer entry points reject bad shapes / pointer combinations the same way
+    rc = lib.tic_conv_igemm_fwd(16, 16, 16, 2, 8, 8, 48, 64, 3, 3, 1, 1, None)          # Cin = 48: not a multiple of 64
+    assert rc == -1 and b"Cin" in lib.tic_last_error_string()
+    rc = lib.tic_conv_igemm_wgrad(16, 16, 16, 2, 8, 8, 64, 60, 3, 3, 1, 1, None)        # Cout = 60: not a multiple of 8
+    assert rc == -1 and b"Cout" in lib.tic_last_error_string()
+    rc = lib.tic_attention_bwd_ws(16, 16, 16, 16, 16, None, 16, 0, 1, 1, 197, 0.125, None)   # scratch without dbias
+    assert rc == -1 and b"scratch" in lib.tic_last_error_string()
+    rc = lib.tic_gemm_nt_bf16_ex(16, 16, 10, 256, 64, 2, None, None, None, 16, 16, None, None, 0, 16, None)   # colsum with EPI_RESID
+    assert rc == -1 and b"colsum" in lib.tic_last_error_string()
+    assert lib.tic_kernel_timer_read(None, None) == -1
+    assert lib.tic_set_option(b"no_such_knob", 1) == -1 and lib.tic_set_option(b"stream_nt", 13) == 0
 
 
 def test_product_path_has_no_cpu_fallback():
