@@ -205,8 +205,20 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     return tic_after_launch("gemm_nt");
 }
 
+static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N, const int* K, int M,
+                              bool force256, tic_stream_t stream);
 extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, tic_stream_t stream) {
     TIC_REQUIRE(A && B && C, "gemm_tn: null operand");
+    // long reductions over 256-aligned outputs (the 1x1-convolution weight gradients of ResNet: a handful of tiles, M up to 10^5
+    // rows) go to the deep-pipelined 256x256 kernel through its stream-K split, which needs no minimum tile count
+    if (g_opt_gemm_tile != 128 && g_opt_tn_streamk && N % 256 == 0 && K % 256 == 0 && M >= 8192 &&
+        (long)(N / 256) * (K / 256) * ((M + 63) / 64) >= 256 && ((double)M + 320.0) * (N > K ? N : K) * 2.0 < 4294967296.0) {
+        const void* a1[1] = {A};
+        const void* b1[1] = {B};
+        float* c1[1] = {C};
+        const int n1[1] = {N}, k1[1] = {K};
+        return gemm_tn_group_impl(1, a1, b1, c1, n1, k1, M, true, stream);
+    }
     TIC_REQUIRE(M >= 1 && N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8, "gemm_tn: need N, K multiples of 8 (M=%d N=%d K=%d)", M, N, K);
     TIC_REQUIRE(TIC_ALIGNED16(A) && TIC_ALIGNED16(B), "gemm_tn: operands must be 16-byte aligned");
     TIC_REQUIRE(((double)M + 64.0) * (N > K ? N : K) * 2.0 < 4294967296.0, "gemm_tn: operand exceeds the 4 GiB buffer-resource range");
@@ -229,6 +241,10 @@ extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, i
 // occupy the chip; otherwise one split-M launch per problem
 extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N,
                                       const int* K, int M, tic_stream_t stream) {
+    return gemm_tn_group_impl(nprob, A, B, C, N, K, M, false, stream);
+}
+static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N, const int* K, int M,
+                              bool force256, tic_stream_t stream) {
     TIC_REQUIRE(nprob >= 1 && nprob <= TN_MAX_GROUP && A && B && C && N && K && M >= 1, "gemm_tn_group: bad argument (nprob=%d)", nprob);
     bool ok256 = true;
     int tiles = 0;
@@ -239,7 +255,7 @@ extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const voi
         if (N[g] % 256 || K[g] % 256) ok256 = false;
         tiles += (N[g] / 256) * (K[g] / 256);
     }
-    if (ok256 && g_opt_gemm_tile != 128 && (g_opt_gemm_tile == 256 || (tiles >= 96 && M >= 2048))) {
+    if (ok256 && g_opt_gemm_tile != 128 && (force256 || g_opt_gemm_tile == 256 || (tiles >= 96 && M >= 2048))) {
         GemmTnGroupParams gp;
         memset(&gp, 0, sizeof(gp));
         int t = 0;
