@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
 //   time and so do the tail CUs (lock-step row slabs are what the L2 / Infinity Cache can share: the flat split below
 //   fetched 2x the bytes of the lock-step kernel because its shares start at 256 different row offsets).
 // s_main == 0 -- FLAT split: the flattened (tile, step) space cut into gridDim.x equal contiguous shares.
-__global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
+TIC_DEV void tn256_streamk_body(const GemmTnGroupParams& gp, int nsteps, int s_main, int tpx, int tail_each) {
     const bf16_t *Ap, *Bp;
     float* Cp;
     int N, K, n0, k0;
@@ -337,4 +337,14 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_kernel(GemmTnGroupP
         tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s0, s1);
         u += s1 - s0;
     }
+}
+
+// the grouped launch of one transformer block (the step's dominant kernel: bench.py times exactly these launches) ...
+__global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
+    tn256_streamk_body(gp, nsteps, s_main, tpx, tail_each);
+}
+// ... and the same code under its own name for single weight-gradient problems routed here by tic_gemm_tn_bf16 (patch embedding,
+// ResNet 1x1 convolutions), so that per-kernel profiler averages of the block launch stay clean
+__global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_single_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
+    tn256_streamk_body(gp, nsteps, s_main, tpx, tail_each);
 }

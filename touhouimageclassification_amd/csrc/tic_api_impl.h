@@ -279,10 +279,15 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
                     if (s_main < 1 || s_main >= nsteps) s_main = 0;
                 }
             }
+            if (force256) {   // single-problem route: same code, own kernel name, not part of the live timer
+                TIC_RT_MAX_LDS(gemm_tn256_streamk_single_kernel, G256_LDS_BYTES);
+                TIC_LAUNCH(gemm_tn256_streamk_single_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
+                return tic_after_launch("gemm_tn(stream-K)");
+            }
             TIC_RT_MAX_LDS(gemm_tn256_streamk_kernel, G256_LDS_BYTES);
-            if (!force256) TIC_RT_TIMER_MARK(0, stream);   // the live timer is for the grouped block launches, not the single-problem route
+            TIC_RT_TIMER_MARK(0, stream);
             TIC_LAUNCH(gemm_tn256_streamk_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
-            if (!force256) TIC_RT_TIMER_MARK(1, stream);
+            TIC_RT_TIMER_MARK(1, stream);
             return tic_after_launch("gemm_tn_group(stream-K)");
         }
         if (g_opt_gemm_dbg) {
