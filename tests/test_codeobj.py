@@ -1,0 +1,49 @@
+"""Static guard on the built gfx950 code object: no kernel may touch scratch or spill, and the kernels whose launch shapes
+assume a register budget keep it.  (A by-value argument struct forwarded to a helper once put the dominant weight-gradient
+kernel's lookup table in scratch: 232 -> 253 VGPRs, 136 B/lane, 8 % slower -- invisible to every numerical test.)"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    from touhouimageclassification_amd import build
+    import codeobj_report
+    ks = codeobj_report.kernels(build.build_hip())
+    names = codeobj_report.demangle([k["name"] for k in ks])
+    return {n: k for n, k in zip(names, ks)}
+
+
+def test_no_scratch_no_spills(kernels):
+    assert len(kernels) > 40
+    # (SGPR spills go to VGPR lanes, not to memory: attn_fwd_kernel has a few and they are harmless)
+    bad = {n: (k["private_segment_fixed_size"], k["vgpr_spill_count"]) for n, k in kernels.items()
+           if k["private_segment_fixed_size"] or k["vgpr_spill_count"]}
+    assert not bad, bad
+
+
+def test_register_budgets(kernels):
+    def get(prefix):
+        hit = [k for n, k in kernels.items() if n.startswith(prefix)]
+        assert hit, prefix
+        return hit
+
+    # 512-thread workgroups, 2 waves per SIMD: the 256-VGPR half of the unified file (accumulators live in arch VGPRs)
+    for prefix in ("void gemm_nt256_kernel<", "gemm_tn256_streamk_kernel", "gemm_tn256_streamk_single_kernel", "void gemm_tn256_kernel<0>"):
+        for k in get(prefix):
+            assert k["vgpr_count"] + k["agpr_count"] <= 256, (prefix, k)
+    for k in get("gemm_tn256_streamk"):          # both names are the same code
+        assert k["vgpr_count"] <= 236, k
+    assert len({k["vgpr_count"] for k in get("gemm_tn256_streamk")}) == 1
+    for k in get("attn_bwd_kernel"):             # 1024 threads -> 4 waves/SIMD -> 128 registers
+        assert k["vgpr_count"] <= 128, k
+    for k in get("attn_fwd_kernel"):             # 256 threads, launch bound 2 workgroups per CU
+        assert k["vgpr_count"] <= 256, k
+    for prefix in ("void gemm_nt_kernel<", "void gemm_tn_kernel<"):   # 256-thread 128^2 tiles: 4 waves/SIMD wanted
+        for k in get(prefix):
+            assert k["vgpr_count"] <= 128, (prefix, k)

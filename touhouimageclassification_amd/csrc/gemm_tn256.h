@@ -309,42 +309,43 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
 //   time and so do the tail CUs (lock-step row slabs are what the L2 / Infinity Cache can share: the flat split below
 //   fetched 2x the bytes of the lock-step kernel because its shares start at 256 different row offsets).
 // s_main == 0 -- FLAT split: the flattened (tile, step) space cut into gridDim.x equal contiguous shares.
-TIC_DEV void tn256_streamk_body(const GemmTnGroupParams& gp, int nsteps, int s_main, int tpx, int tail_each) {
-    const bf16_t *Ap, *Bp;
-    float* Cp;
-    int N, K, n0, k0;
-    if (s_main > 0) {
-        const int xcd = TIC_BID_X & 7, idx = TIC_BID_X >> 3;   // blocks b, b+8, ... share an XCD (speed only, never correctness)
-        if (idx < tpx) {
-            tn_tile_lookup(gp, xcd * tpx + idx, Ap, Bp, Cp, N, K, n0, k0);
-            tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, s_main);
-        } else {
-            for (int j = 0; j < tail_each; ++j) {
-                tn_tile_lookup(gp, xcd * tpx + (idx - tpx) * tail_each + j, Ap, Bp, Cp, N, K, n0, k0);
-                tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s_main, nsteps);
-            }
-        }
-        return;
+// body shared by the two kernel names below (a macro, not a function: passing the by-value kernel argument struct on to a
+// function makes hipcc copy it to scratch -- +136 B/lane, +21 VGPRs, 8 % slower)
+#define TN256_STREAMK_BODY \
+    const bf16_t *Ap, *Bp; \
+    float* Cp; \
+    int N, K, n0, k0; \
+    if (s_main > 0) { \
+        const int xcd = TIC_BID_X & 7, idx = TIC_BID_X >> 3;   /* blocks b, b+8, ... share an XCD (speed only, never correctness) */ \
+        if (idx < tpx) { \
+            tn_tile_lookup(gp, xcd * tpx + idx, Ap, Bp, Cp, N, K, n0, k0); \
+            tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, s_main); \
+        } else { \
+            for (int j = 0; j < tail_each; ++j) { \
+                tn_tile_lookup(gp, xcd * tpx + (idx - tpx) * tail_each + j, Ap, Bp, Cp, N, K, n0, k0); \
+                tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s_main, nsteps); \
+            } \
+        } \
+        return; \
+    } \
+    const long total_units = (long)gp.total_tiles * nsteps; \
+    int u = (int)(total_units * TIC_BID_X / TIC_NBLK_X); \
+    const int u1 = (int)(total_units * (TIC_BID_X + 1) / TIC_NBLK_X); \
+    while (u < u1) {   /* wave-uniform */ \
+        const int tile = u / nsteps, s0 = u - tile * nsteps; \
+        int s1 = s0 + (u1 - u); \
+        if (s1 > nsteps) s1 = nsteps; \
+        tn_tile_lookup(gp, tile, Ap, Bp, Cp, N, K, n0, k0); \
+        tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s0, s1); \
+        u += s1 - s0; \
     }
-    const long total_units = (long)gp.total_tiles * nsteps;
-    int u = (int)(total_units * TIC_BID_X / TIC_NBLK_X);
-    const int u1 = (int)(total_units * (TIC_BID_X + 1) / TIC_NBLK_X);
-    while (u < u1) {   // wave-uniform
-        const int tile = u / nsteps, s0 = u - tile * nsteps;
-        int s1 = s0 + (u1 - u);
-        if (s1 > nsteps) s1 = nsteps;
-        tn_tile_lookup(gp, tile, Ap, Bp, Cp, N, K, n0, k0);
-        tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s0, s1);
-        u += s1 - s0;
-    }
-}
 
 // the grouped launch of one transformer block (the step's dominant kernel: bench.py times exactly these launches) ...
 __global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
-    tn256_streamk_body(gp, nsteps, s_main, tpx, tail_each);
+    TN256_STREAMK_BODY
 }
 // ... and the same code under its own name for single weight-gradient problems routed here by tic_gemm_tn_bf16 (patch embedding,
 // ResNet 1x1 convolutions), so that per-kernel profiler averages of the block launch stay clean
 __global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_single_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
-    tn256_streamk_body(gp, nsteps, s_main, tpx, tail_each);
+    TN256_STREAMK_BODY
 }
