@@ -144,6 +144,7 @@ def check_attention_fwd_bwd(env, B, H, N):
     torch.testing.assert_close(dqkv.float(), qr.grad, atol=0.03, rtol=0.05)
 
 
+
 def check_elementwise_ops(env):
     rnd, call, dev = env.rnd, env.call, env.dev
     # patchify

@@ -170,8 +170,8 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     const int bh = TIC_BID_X, b = bh / p.H, h = bh - b * p.H;
     const int N = p.N, D = p.D, ld = 3 * D;
     const long row0 = (long)b * N;
-    const uint32_t QT = 0, KT = ATT_TILE_BYTES, VT = 2 * ATT_TILE_BYTES, DOT = 3 * ATT_TILE_BYTES;
-    const uint32_t LSE = 4 * ATT_TILE_BYTES, DEL = LSE + ATT_ROWS * 4, DBL = DEL + ATT_ROWS * 4;   // DBL: [3][64] floats
+    constexpr uint32_t QT = 0, DOT = ATT_TILE_BYTES, KT = 2 * ATT_TILE_BYTES, VT = 3 * ATT_TILE_BYTES;   // Q, dO | K, V: each sweep's pair within one 64 KiB immediate range
+    constexpr uint32_t LSE = 4 * ATT_TILE_BYTES, DEL = LSE + ATT_ROWS * 4, DBL = DEL + ATT_ROWS * 4;   // DBL: [3][64] floats
     const tic_rsrc_t rq = make_rsrc(p.qkv, (uint32_t)((size_t)p.B * N * ld * 2));
     const tic_rsrc_t rdo = make_rsrc(p.d_o, (uint32_t)((size_t)p.B * N * D * 2));
     att_stage_tile<16>(rq, QT, row0, N, ld, h * ATT_HD, l, w);
@@ -208,6 +208,24 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     const float c = p.scale * 1.4426950408889634f;
     const int n16 = (N + 15) >> 4, n32 = (N + 31) >> 5;   // 13 / 7 at N = 197: tiles / tile pairs that hold real tokens
 
+    // The sweeps below are VALU-bound, not MFMA-bound (first version: 86 VALU instructions per 16 MFMAs, 30 of them LDS address
+    // updates -- one induction variable per read -- 8 selects for the padding mask and 8 multiplies by the softmax scale).  So:
+    //  * every LDS address is (lane constant) + (ONE scalar sweep offset, laundered through an empty asm so that the
+    //    compiler cannot strength-reduce it back into 28 vector induction variables) + an instruction immediate.  The swizzle
+    //    only looks at row bits 1-2, so +16 / +32 rows are plain byte offsets; the tile order Q, dO | K, V keeps both tiles of
+    //    a sweep inside the 64 KiB immediate range of one base;
+    //  * the padding mask is compiled only into the tiles that have padding (MASK = false elsewhere);
+    //  * the softmax scale multiplies dK / dQ once at the end instead of every dS (exact for power-of-two scales).
+    uint32_t l_row[2], l_tr[4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) l_row[ks] = att_row_off((uint32_t)li, (uint32_t)(ks * 4 + g));
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) l_tr[dt] = att_tr_off(4u * g + (((uint32_t)l >> 2) & 3u), 16u * dt + 4u * ((uint32_t)l & 3u));
+    const uint32_t l_ls = LSE + 16u * (uint32_t)g;
+    auto tr_frag = [&](uint32_t base, int dt) {   // = att_tr_frag(tile, blk32, dt, l) with base = tile + 4096 * blk32 + l_tr[dt]
+        return cat4(lds_tr64(base), lds_tr64(base + 2048u));
+    };
+
     // ---------------- phase A: dK, dV (key on the lane) -- waves 0..7 ----------------
     // q/k/v bias gradient = column sums of dq / dk / dv.  Every finished tile is reduced at once: 16-lane rows by DPP, then the
     // wave adds into ITS OWN LDS slot (lane 0 of each row, read-modify-write, no atomics: phase-A wave w and phase-B wave
@@ -241,36 +259,46 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
             dva[dt] = f32x4{0, 0, 0, 0};
             dka[dt] = f32x4{0, 0, 0, 0};
         }
+        auto sweep = [&](auto mask_tag) {
+            constexpr bool MASK = decltype(mask_tag)::value;
 #pragma nounroll
-        for (int qp = 0; qp < n32; ++qp) {
-            f32x4 pv[2], dsv[2];
+            for (int qp = 0; qp < n32; ++qp) {
+                uint32_t qb = (uint32_t)qp * 4096u;   // 32 query rows x 128 B
+                opaque_s(qb);
+                f32x4 pv[2], dsv[2];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int qrow = (2 * qp + hh) * 16;
-                f32x4 sa = f32x4{0, 0, 0, 0}, da = f32x4{0, 0, 0, 0};
+                for (int hh = 0; hh < 2; ++hh) {
+                    f32x4 sa = f32x4{0, 0, 0, 0}, da = f32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 fq = lds_ld128(QT + att_row_off((uint32_t)(qrow + li), (uint32_t)(ks * 4 + g)));
-                    const bf16x8 fd = lds_ld128(DOT + att_row_off((uint32_t)(qrow + li), (uint32_t)(ks * 4 + g)));
-                    sa = mfma16(fq, fk[ks], sa);   // S[q = qrow + 4g + r][key]
-                    da = mfma16(fd, fv[ks], da);   // dP[q][key]
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8 fq = lds_ld128(l_row[ks] + qb + (QT + 2048u * hh));
+                        const bf16x8 fd = lds_ld128(l_row[ks] + qb + (DOT + 2048u * hh));
+                        sa = mfma16(fq, fk[ks], sa);   // S[q = 32 qp + 16 hh + 4g + r][key]
+                        da = mfma16(fd, fv[ks], da);   // dP[q][key]
+                    }
+                    const uint32_t lb = l_ls + (qb >> 5);   // 4 B per query row
+                    const f32x4 ls4 = lds_ldf4(lb + 64u * hh);
+                    const f32x4 dl4 = lds_ldf4(lb + (ATT_ROWS * 4u + 64u * hh));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pr = fast_exp2(sa[r] * c - ls4[r]);
+                        if (MASK) pr = key_ok ? pr : 0.f;
+                        pv[hh][r] = pr;
+                        dsv[hh][r] = pr * (da[r] - dl4[r]);   // x scale at the end
+                    }
                 }
-                const f32x4 ls4 = lds_ldf4(LSE + 4u * (uint32_t)(qrow + 4 * g));
-                const f32x4 dl4 = lds_ldf4(DEL + 4u * (uint32_t)(qrow + 4 * g));
+                const bf16x8 fp = pack8(pv[0], pv[1]), fds = pack8(dsv[0], dsv[1]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pr = key_ok ? fast_exp2(sa[r] * c - ls4[r]) : 0.f;
-                    pv[hh][r] = pr;
-                    dsv[hh][r] = pr * (da[r] - dl4[r]) * p.scale;
+                for (int dt = 0; dt < 4; ++dt) {
+                    dva[dt] = mfma16(tr_frag(l_tr[dt] + qb + DOT, dt), fp, dva[dt]);    // dV^T[d][key]
+                    dka[dt] = mfma16(tr_frag(l_tr[dt] + qb + QT, dt), fds, dka[dt]);    // dK^T[d][key]
                 }
             }
-            const bf16x8 fp = pack8(pv[0], pv[1]), fds = pack8(dsv[0], dsv[1]);
+        };
+        if (kt * 16 + 16 <= N) sweep(tic_false{});   // wave-uniform
+        else sweep(tic_true{});
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dva[dt] = mfma16(att_tr_frag(DOT, qp, dt, l), fp, dva[dt]);    // dV^T[d][key]
-                dka[dt] = mfma16(att_tr_frag(QT, qp, dt, l), fds, dka[dt]);    // dK^T[d][key]
-            }
-        }
+        for (int dt = 0; dt < 4; ++dt) dka[dt] *= p.scale;
         if (p.dbias) {   // kernel argument: uniform.  padded keys contribute exact zeros (p = 0)
             reduce_cols(dka, 64u);
             if (!p.skip_v_bias) reduce_cols(dva, 128u);
@@ -288,8 +316,8 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
 
     // ---------------- phase B: dQ (query on the lane) -- waves 8..15 ----------------
     if (w >= 8)
-    for (int qb = w - 8; qb < n16; qb += 8) {
-        const int q = qb * 16 + li;
+    for (int qb16 = w - 8; qb16 < n16; qb16 += 8) {
+        const int q = qb16 * 16 + li;
         bf16x8 fq[2], fd[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -300,30 +328,40 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
         f32x4 dqa[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dqa[dt] = f32x4{0, 0, 0, 0};
+        auto sweep = [&](auto mask_tag, int kp0, int kp1) {
+            constexpr bool MASK = decltype(mask_tag)::value;
 #pragma nounroll
-        for (int kp = 0; kp < n32; ++kp) {
-            f32x4 dsv[2];
+            for (int kp = kp0; kp < kp1; ++kp) {
+                uint32_t kb = (uint32_t)kp * 4096u;   // 32 key rows x 128 B
+                opaque_s(kb);
+                f32x4 dsv[2];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int krow = (2 * kp + hh) * 16;
-                f32x4 sa = f32x4{0, 0, 0, 0}, da = f32x4{0, 0, 0, 0};
+                for (int hh = 0; hh < 2; ++hh) {
+                    f32x4 sa = f32x4{0, 0, 0, 0}, da = f32x4{0, 0, 0, 0};
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 fk = lds_ld128(KT + att_row_off((uint32_t)(krow + li), (uint32_t)(ks * 4 + g)));
-                    const bf16x8 fv = lds_ld128(VT + att_row_off((uint32_t)(krow + li), (uint32_t)(ks * 4 + g)));
-                    sa = mfma16(fk, fq[ks], sa);   // S^T[key = krow + 4g + r][q]
-                    da = mfma16(fv, fd[ks], da);   // dP^T[key][q]
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const bf16x8 fk = lds_ld128(l_row[ks] + kb + (KT + 2048u * hh));
+                        const bf16x8 fv = lds_ld128(l_row[ks] + kb + (VT + 2048u * hh));
+                        sa = mfma16(fk, fq[ks], sa);   // S^T[key = 32 kp + 16 hh + 4g + r][q]
+                        da = mfma16(fv, fd[ks], da);   // dP^T[key][q]
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pr = fast_exp2(sa[r] * c - ls);
+                        if (MASK) pr = (kp * 32 + hh * 16 + 4 * g + r < N) ? pr : 0.f;
+                        dsv[hh][r] = pr * (da[r] - dl);   // x scale at the end
+                    }
                 }
+                const bf16x8 fds = pack8(dsv[0], dsv[1]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pr = (krow + 4 * g + r < N) ? fast_exp2(sa[r] * c - ls) : 0.f;
-                    dsv[hh][r] = pr * (da[r] - dl) * p.scale;
-                }
+                for (int dt = 0; dt < 4; ++dt) dqa[dt] = mfma16(tr_frag(l_tr[dt] + kb + KT, dt), fds, dqa[dt]);   // dQ^T[d][q]
             }
-            const bf16x8 fds = pack8(dsv[0], dsv[1]);
+        };
+        const int nfull = N >> 5;   // key pairs without padding
+        sweep(tic_false{}, 0, nfull);
+        sweep(tic_true{}, nfull, n32);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dqa[dt] = mfma16(att_tr_frag(KT, kp, dt, l), fds, dqa[dt]);   // dQ^T[d][q]
-        }
+        for (int dt = 0; dt < 4; ++dt) dqa[dt] *= p.scale;
         if (p.dbias) reduce_cols(dqa, 0u);
         if (q < N) {
             bf16_t* qrow = p.dqkv + (size_t)(row0 + q) * ld + h * ATT_HD + 4 * g;

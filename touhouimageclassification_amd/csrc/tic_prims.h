@@ -192,6 +192,17 @@ TIC_DEV uint32_t pack2bf(float lo, float hi) {   // ONE v_cvt_pk_bf16_f32 (two s
 }
 #endif
 
+// compile-time switches passed to generic lambdas (`[&](auto tag) { constexpr bool X = decltype(tag)::value; ... }`)
+struct tic_false { static constexpr bool value = false; };
+struct tic_true { static constexpr bool value = true; };
+// a wave-uniform value the optimiser must treat as unknown (stays in an SGPR): keeps ONE scalar sweep offset from being
+// strength-reduced into a vector induction variable per LDS read
+TIC_DEV void opaque_s(uint32_t& v) {
+#ifndef TIC_SIM
+    asm volatile("" : "+s"(v));
+#endif
+}
+
 // streaming accesses: data touched once per pass (the fp32 residual stream and its gradient); NT = non-temporal hint
 template <bool NT> TIC_DEV f32x4 ld_f4(const float* p) {
 #ifndef TIC_SIM
