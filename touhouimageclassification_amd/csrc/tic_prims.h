@@ -203,6 +203,13 @@ TIC_DEV void opaque_s(uint32_t& v) {
 #endif
 }
 
+// placed inside a wave-uniform `if` body: keeps the compiler from if-converting the branch into per-lane selects
+TIC_DEV void keep_branch() {
+#ifndef TIC_SIM
+    asm volatile("");
+#endif
+}
+
 // streaming accesses: data touched once per pass (the fp32 residual stream and its gradient); NT = non-temporal hint
 template <bool NT> TIC_DEV f32x4 ld_f4(const float* p) {
 #ifndef TIC_SIM
