@@ -36,6 +36,7 @@ const char* tic_last_error_string(void);
  *   "tn_streamk" 1 (256 shares) | 0 | n     stream-K split of the grouped dW launch
  *   "tn_phase"   1 | 0                      phase-aligned vs flat stream-K split
  *   "stream_nt"  bit mask, default 13       non-temporal cache policy: 1 LayerNorm, 2 AdamW, 4 GEMM epilogue stores, 8 epilogue operand loads
+ *   "attn_fwd_waves" 8 | 4                   waves per (image, head) workgroup of the attention forward
  *   "gemm_stagger" -1 (auto) | 0 | n        s_sleep rounds by which every other first-wave workgroup of the 256x256 NT kernel starts late
  *   "gemm_dbg"   0..15                      measurement builds of the 256x256 kernels with parts of the main loop compiled
  *                                           out (bit 0 no LDS-DMA, 1 no fragment reads, 2 no MFMA, 3 deeper queue): GARBAGE

@@ -21,6 +21,8 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+if len(sys.argv) > 2:
+    call("tic_set_option", b"attn_fwd_waves", int(sys.argv[2]))   # 4 (default) or 8 waves per forward workgroup
 fwd = t(lambda: call("tic_attention_fwd", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, N, 0.125, current_stream()))
 bwd = t(lambda: call("tic_attention_bwd_ex", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), B, H, N, 0.125, current_stream()))
 bwd0 = t(lambda: call("tic_attention_bwd_ex", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), do.data_ptr(), dqkv.data_ptr(), None, B, H, N, 0.125, current_stream()))

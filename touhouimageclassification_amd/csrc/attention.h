@@ -77,15 +77,16 @@ TIC_DEV bf16x8 att_tr_frag(uint32_t tile_off, int blk32, int dt, int l) {
     return cat4(lo, hi);
 }
 
-__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnParams p) {
     const int l = lane_id(), w = wave_id();
     const int bh = TIC_BID_X, b = bh / p.H, h = bh - b * p.H;
     const int N = p.N, D = p.D, ld = 3 * D;
     const long row0 = (long)b * N;
     const uint32_t KT = 0, VT = ATT_TILE_BYTES;
     const tic_rsrc_t rq = make_rsrc(p.qkv, (uint32_t)((size_t)p.B * N * ld * 2));
-    att_stage_tile<4>(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
-    att_stage_tile<4>(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
+    att_stage_tile<NW>(rq, KT, row0, N, ld, D + h * ATT_HD, l, w);
+    att_stage_tile<NW>(rq, VT, row0, N, ld, 2 * D + h * ATT_HD, l, w);
     wait_vmcnt0();
     block_sync();
 
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnParams p) {
     const float NEG_INF = -__builtin_huge_valf();
     const int n16 = (N + 15) >> 4;   // 13 at N = 197; shorter sequences skip the all-padding query blocks
     const int n_full = N >> 4;       // key tiles without padding
-    for (int qb = w; qb < n16; qb += 4) {
+    for (int qb = w; qb < n16; qb += NW) {
         const int q = qb * 16 + qi;
         // Q fragments (B operand of S^T = K.Q^T): query q, d = 32ks + 8g .. +7, straight from HBM
         bf16x8 fq[2];

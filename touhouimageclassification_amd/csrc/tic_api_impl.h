@@ -49,6 +49,7 @@ static int g_opt_nt = 13;         // non-temporal loads / stores for once-touche
                                   // 2 AdamW (no effect: off), 4 staged GEMM epilogue stores (-0.8 %), 8 its residual / derivative operand loads (-0.1 %)
 static int g_opt_ln_blocks = 4096;   // grid cap of the LayerNorm kernels (4 rows per block per pass)
 static int g_opt_gemm_gm = 8;
+static int g_opt_attn_fwd_waves = 8;   // attention forward: waves per (image, head) workgroup, 4 or 8 (two workgroups per CU either way; 8: 179 -> 150 us)
 static int g_opt_tn_main_bias = 0;   // extra M steps given to the 'main' workgroups of the phase-aligned stream-K split (tail ones pay 3 prologues / epilogues)
 static int g_opt_gemm_dbg = 0;
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
@@ -57,6 +58,10 @@ static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the til
 extern "C" int tic_set_option(const char* name, int value) {
     if (name && !strcmp(name, "ln_blocks") && value >= 64 && value <= 65536) {
         g_opt_ln_blocks = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "attn_fwd_waves") && (value == 4 || value == 8)) {
+        g_opt_attn_fwd_waves = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "tn_main_bias") && value >= 0 && value <= 64) {
@@ -369,8 +374,13 @@ extern "C" int tic_attention_fwd(const void* qkv, void* o, float* lse, int B, in
     AttnParams p;
     memset(&p, 0, sizeof(p));
     p.qkv = (const bf16_t*)qkv; p.o = (bf16_t*)o; p.lse = lse; p.B = B; p.H = H; p.N = N; p.D = H * 64; p.scale = scale;
-    TIC_RT_MAX_LDS(attn_fwd_kernel, 2 * ATT_TILE_BYTES);
-    TIC_LAUNCH(attn_fwd_kernel, B * H, 256, 2 * ATT_TILE_BYTES, stream, p);
+    if (g_opt_attn_fwd_waves == 8) {
+        TIC_RT_MAX_LDS(attn_fwd_kernel<8>, 2 * ATT_TILE_BYTES);
+        TIC_LAUNCH(attn_fwd_kernel<8>, B * H, 512, 2 * ATT_TILE_BYTES, stream, p);
+    } else {
+        TIC_RT_MAX_LDS(attn_fwd_kernel<4>, 2 * ATT_TILE_BYTES);
+        TIC_LAUNCH(attn_fwd_kernel<4>, B * H, 256, 2 * ATT_TILE_BYTES, stream, p);
+    }
     return tic_after_launch("attention_fwd");
 }
 extern "C" int tic_attention_bwd(const void* qkv, const void* o, const float* lse, const void* d_o, void* dqkv, int B,
