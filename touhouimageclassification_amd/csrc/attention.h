@@ -288,11 +288,15 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                     const f32x4 ls4 = lds_ldf4(lb + 64u * hh);
                     const f32x4 dl4 = lds_ldf4(lb + (ATT_ROWS * 4u + 64u * hh));
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float pr = fast_exp2(sa[r] * c - ls4[r]);
-                        if (MASK) pr = key_ok ? pr : 0.f;
-                        pv[hh][r] = pr;
-                        dsv[hh][r] = pr * (da[r] - dl4[r]);   // x scale at the end
+                    for (int r2 = 0; r2 < 4; r2 += 2) {   // two values per instruction (v_pk_fma / v_pk_add / v_pk_mul)
+                        const f32x2 arg = f32x2{sa[r2], sa[r2 + 1]} * c - f32x2{ls4[r2], ls4[r2 + 1]};
+                        f32x2 pr = f32x2{fast_exp2(arg[0]), fast_exp2(arg[1])};
+                        if (MASK) pr = key_ok ? pr : f32x2{0.f, 0.f};
+                        const f32x2 ds = pr * (f32x2{da[r2], da[r2 + 1]} - f32x2{dl4[r2], dl4[r2 + 1]});   // x scale at the end
+                        pv[hh][r2] = pr[0];
+                        pv[hh][r2 + 1] = pr[1];
+                        dsv[hh][r2] = ds[0];
+                        dsv[hh][r2 + 1] = ds[1];
                     }
                 }
                 const bf16x8 fp = pack8(pv[0], pv[1]), fds = pack8(dsv[0], dsv[1]);
@@ -354,10 +358,16 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                         da = mfma16(fv, fd[ks], da);   // dP^T[key][q]
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float pr = fast_exp2(sa[r] * c - ls);
-                        if (MASK) pr = (kp * 32 + hh * 16 + 4 * g + r < N) ? pr : 0.f;
-                        dsv[hh][r] = pr * (da[r] - dl);   // x scale at the end
+                    for (int r2 = 0; r2 < 4; r2 += 2) {
+                        const f32x2 arg = f32x2{sa[r2], sa[r2 + 1]} * c - ls;
+                        f32x2 pr = f32x2{fast_exp2(arg[0]), fast_exp2(arg[1])};
+                        if (MASK) {
+                            const int key = kp * 32 + hh * 16 + 4 * g + r2;
+                            pr = f32x2{key < N ? pr[0] : 0.f, key + 1 < N ? pr[1] : 0.f};
+                        }
+                        const f32x2 ds = pr * (f32x2{da[r2], da[r2 + 1]} - dl);   // x scale at the end
+                        dsv[hh][r2] = ds[0];
+                        dsv[hh][r2 + 1] = ds[1];
                     }
                 }
                 const bf16x8 fds = pack8(dsv[0], dsv[1]);
