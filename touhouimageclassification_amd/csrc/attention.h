@@ -327,8 +327,13 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     }
 
     // ---------------- phase B: dQ (query on the lane) -- waves 8..15 ----------------
+    // Which waves take a SECOND tile decides the load of the four SIMDs (wave w runs on SIMD w % 4; a phase-A tile costs about
+    // 4/3 of a phase-B tile).  Phase A gives its 5 second tiles to waves 0-4 (SIMD loads 4,3,3,3 tiles); if phase B did the
+    // same (waves 8-12) SIMD 0 would carry 4A + 4B against 3A + 3B elsewhere.  With phase B's second tiles on waves 9, 10, 11, 13,
+    // 14 the loads are 4A+2B, 3A+4B, 3A+4B, 3A+3B: the critical SIMD drops from 9.3 to 8 B-tile units.
+    const int rank2 = (0x74362105 >> ((w & 7) * 4)) & 7;   // order in which waves 8..15 receive tiles 8, 9, ...: 9,10,11,13,14,8,12,15
     if (w >= 8)
-    for (int qb16 = w - 8; qb16 < n16; qb16 += 8) {
+    for (int it = 0, qb16 = w - 8; it < 2 && qb16 < n16; ++it, qb16 = 8 + rank2) {
         const int q = qb16 * 16 + li;
         bf16x8 fq[2], fd[2];
 #pragma unroll
