@@ -42,7 +42,9 @@ def test_register_budgets(kernels):
     assert len({k["vgpr_count"] for k in get("gemm_tn256_streamk")}) == 1
     for k in get("attn_bwd_kernel"):             # 1024 threads -> 4 waves/SIMD -> 128 registers
         assert k["vgpr_count"] <= 128, k
-    for k in get("void attn_fwd_kernel<"):            # 256 threads, launch bound 2 workgroups per CU
+    for k in get("void attn_fwd_kernel<8>"):     # two 8-wave workgroups per CU = 4 waves per SIMD
+        assert k["vgpr_count"] <= 128, k
+    for k in get("void attn_fwd_kernel<"):            # 4 or 8 waves, launch bound 2 waves per SIMD
         assert k["vgpr_count"] <= 256, k
     for prefix in ("void gemm_nt_kernel<", "void gemm_tn_kernel<"):   # 256-thread 128^2 tiles: 4 waves/SIMD wanted
         for k in get(prefix):
