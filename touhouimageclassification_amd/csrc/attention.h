@@ -78,7 +78,7 @@ TIC_DEV bf16x8 att_tr_frag(uint32_t tile_off, int blk32, int dt, int l) {
 }
 
 template <int NW>
-__global__ void __launch_bounds__(NW * 64, 2) attn_fwd_kernel(AttnParams p) {
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) attn_fwd_kernel(AttnParams p) {   // two workgroups per CU either way
     const int l = lane_id(), w = wave_id();
     const int bh = TIC_BID_X, b = bh / p.H, h = bh - b * p.H;
     const int N = p.N, D = p.D, ld = 3 * D;
