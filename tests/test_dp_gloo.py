@@ -71,3 +71,57 @@ def test_dp_ranks_match_single_process(tmp_path, world):
     rel = ((r0["grads"] - ref).norm() / ref.norm()).item()
     assert rel < 2e-2, rel     # same math; bf16 rounding of per-rank partial sums differs from the global-batch order
     assert abs(sum(rk["loss"] for rk in ranks) / world - float(loss)) < 1e-3
+
+
+class _Recording(torch.utils.data.Dataset):
+    """records which samples a rank really touched"""
+
+    def __init__(self, ds, log):
+        self.ds, self.log = ds, log
+
+    def __len__(self):
+        return len(self.ds)
+
+    def __getitem__(self, i):
+        self.log.append(int(i))
+        return self.ds[i]
+
+
+def _fit_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests.simlib import SimBackend
+    from touhouimageclassification_amd.ViT import ntrain
+    be = SimBackend()
+    ntrain.seed_everything(42)
+    lm = ntrain.ViTLModule(10, False, "micro", lr=1e-3, weight_decay=0.01, enable_mixup=False, backend=be)
+    seen = []
+    ds = _Recording(ntrain.SyntheticU8(12, 10, size=40, seed=1), seen)
+    data = ntrain.AugmentedDataset(batch_size=2, train_split=0.67, num_workers=0, image_size=(32, 32), backend=be, dataset=ds, test_dataset=ds)
+    tr = ntrain.Trainer(max_epochs=2, checkpoint_dir=os.path.join(out_dir, "ck"), train_id="dp", patience=0, device=torch.device("cpu"),
+                        log=lambda s: open(os.path.join(out_dir, f"log{rank}.txt"), "a").write(s + "\n"))
+    hist = tr.fit(lm, data)
+    split = list(data.train_dataset.indices), list(data.val_dataset.indices)
+    torch.save({"params": lm.vit._engine.params.clone(), "hist": hist, "seen": seen, "split": split}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_trainer_fit_shards_the_epoch_and_keeps_replicas_identical(tmp_path):
+    """VERDICT r1 weak #9: Trainer.fit under torch.distributed -- rank-sharded loaders, reduced metrics, rank-0 checkpoints"""
+    world = 2
+    mp.start_processes(_fit_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    r = [torch.load(tmp_path / f"rank{k}.pt", weights_only=False) for k in range(world)]
+    assert torch.equal(r[0]["params"], r[1]["params"])                 # same broadcast start, same all-reduced gradients
+    assert r[0]["hist"] == r[1]["hist"] and len(r[0]["hist"]) == 2      # metrics are global means, identical on every rank
+    assert r[0]["split"] == r[1]["split"]
+    train_idx, val_idx = r[0]["split"]
+    # every epoch each rank touches half of the split, the two halves are disjoint, together they cover it
+    per_epoch = (len(train_idx) + len(val_idx)) // world
+    for e in range(2):
+        a = [r[k]["seen"][e * per_epoch:(e + 1) * per_epoch] for k in range(world)]
+        assert not set(a[0]) & set(a[1])
+        assert set(a[0]) | set(a[1]) == set(train_idx) | set(val_idx)
+    assert not os.path.exists(tmp_path / "log1.txt") and len(open(tmp_path / "log0.txt").read().strip().split("\n")) == 2
+    assert len([f for f in os.listdir(tmp_path / "ck") if f.endswith(".ckpt")]) >= 1

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import json
 import os
+from collections import OrderedDict
 from types import SimpleNamespace
 from typing import Dict, Optional
 
@@ -54,18 +55,19 @@ class _VitFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, x, module):
         ctx.module = module
-        return module._engine.forward(x)
+        logits, ctx.stamp = module._engine.forward_stamped(x)
+        return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        ctx.module._run_backward(dlogits)
+        ctx.module._run_backward(dlogits, ctx.stamp)
         return None, None, None
 
 
-def _old_to_new_key(k: str) -> str:
+def _old_to_new_key(k: str, strip_lightning: bool = True) -> str:
     """transformers-4.x checkpoint keys (what the authors' .pth files hold, finetune.py:250) and
     Lightning's extra ``vit.`` prefix (ntrain.py:27,192-193) -> 5.x keys."""
-    if k.startswith("vit.vit.") or k.startswith("vit.classifier."):
+    if strip_lightning and (k.startswith("vit.vit.") or k.startswith("vit.classifier.")):
         k = k[4:]
     k = k.replace("vit.encoder.layer.", "vit.layers.")
     for old, new in ((".attention.attention.query.", ".attention.q_proj."), (".attention.attention.key.", ".attention.k_proj."),
@@ -73,6 +75,16 @@ def _old_to_new_key(k: str) -> str:
                      (".intermediate.dense.", ".mlp.fc1."), (".output.dense.", ".mlp.fc2.")):
         k = k.replace(old, new)
     return k
+
+
+def _translate_keys_hook(module, state_dict, prefix, *_):
+    """load_state_dict pre-hook: 4.x names under this module's prefix -> 5.x names, in place.  As a hook (not only an
+    override of ``load_state_dict``) it also runs when the model is a CHILD of the module being loaded, e.g. a Lightning
+    checkpoint restored through ``ViTLModule.load_state_dict`` (ntrain.py:27,232)."""
+    for k in [k for k in state_dict if k.startswith(prefix)]:
+        nk = prefix + _old_to_new_key(k[len(prefix):], strip_lightning=False)
+        if nk != k:
+            state_dict[nk] = state_dict.pop(k)
 
 
 class TicViTForImageClassification(nn.Module):
@@ -89,6 +101,11 @@ class TicViTForImageClassification(nn.Module):
         self._anchor = torch.zeros(1, requires_grad=True)
         self._bucket_hook = None
         self._build_tree()
+        plist = list(self._params_by_name.values())
+        # in-place updates through a Parameter (torch.optim.*, p.data.copy_, load_state_dict) bump THAT Parameter's version
+        # counter; after `.to()` it is no longer the flat buffer's, so the bf16 operand copies follow the sum of both
+        self._engine.version_probe = lambda: sum(p._version for p in plist)
+        self.register_load_state_dict_pre_hook(_translate_keys_hook)
         self.reset_parameters()
 
     # ---- module tree with HF names; every Parameter is a view of the engine's flat buffer ----------------
@@ -154,7 +171,7 @@ class TicViTForImageClassification(nn.Module):
         self._engine.mark_weights_dirty()
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        sd = {_old_to_new_key(k): v for k, v in state_dict.items()}
+        sd = OrderedDict((_old_to_new_key(k), v) for k, v in state_dict.items())   # Lightning prefix; 4.x names: the pre-hook
         out = super().load_state_dict(sd, strict=strict, assign=False)
         self._engine.mark_weights_dirty()
         return out
@@ -185,7 +202,7 @@ class TicViTForImageClassification(nn.Module):
             loss = torch.nn.functional.cross_entropy(logits, labels)
         return ImageClassifierOutput(logits, loss)
 
-    def _run_backward(self, dlogits: torch.Tensor):
+    def _run_backward(self, dlogits: torch.Tensor, stamp=None):
         e = self._engine
         params = self._params_by_name
         head_only = not any(p.requires_grad for n, p in params.items() if n.startswith("vit.embeddings") or n.startswith("vit.layers"))
@@ -197,7 +214,7 @@ class TicViTForImageClassification(nn.Module):
         if self._bucket_hook is not None:
             user = self._bucket_hook
             hook = lambda name, a, b: user(name, e.grads[a:b])   # noqa: E731
-        e.backward(dlogits.to(torch.float32).contiguous(), bucket_hook=hook, head_only=head_only)
+        e.backward(dlogits.to(torch.float32).contiguous(), bucket_hook=hook, head_only=head_only, stamp=stamp)
         for name, (off, shape) in self._table.items():
             p = params[name]
             if p.requires_grad and p.grad is None:

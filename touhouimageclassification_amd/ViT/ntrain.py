@@ -25,6 +25,7 @@ import os
 from typing import Dict, List, Optional
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -41,6 +42,14 @@ FILTERED_DATA_DIR = "data/filtered"
 TEST_DIR = "data/test"
 CHECKPOINT_DIR = "checkpoint"
 STAGING_SIZE = 256   # dataset thumbnails are 256x256 (report section 3.1); raw uint8 batches are staged at this size
+
+
+def _world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 class ViTLModule(nn.Module):
@@ -147,6 +156,7 @@ class AugmentedDataset:
         self.enable_generalization, self.only_grey_augmentation = enable_generalization, only_grey_augmentation
         self._backend = backend
         self._dataset_override, self._test_override = dataset, test_dataset
+        self._samplers: List = []
 
     def setup(self, stage: str):
         size = self.image_size[0]
@@ -162,10 +172,21 @@ class AugmentedDataset:
             self.test_dataset = self._test_override or ImageFolderU8(self.test_path)
 
     def _loader(self, ds, shuffle):
-        return torch.utils.data.DataLoader(ds, batch_size=self.batch_size, shuffle=shuffle, num_workers=self.num_workers,
-                                           pin_memory=torch.cuda.is_available())
+        """Under torch.distributed every rank iterates its own 1/world shard of `ds` (DistributedSampler: same permutation on
+        every rank, seeded by the epoch the Trainer sets, rank-strided slices); the reference is single-process (ntrain.py:240)."""
+        sampler = None
+        if _world() > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=_world(), rank=_rank(), shuffle=shuffle, seed=42)
+            self._samplers.append(sampler)
+        return torch.utils.data.DataLoader(ds, batch_size=self.batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                                           num_workers=self.num_workers, pin_memory=torch.cuda.is_available())
+
+    def set_epoch(self, epoch: int) -> None:
+        for s in self._samplers:
+            s.set_epoch(epoch)
 
     def train_dataloader(self):
+        self._samplers.clear()
         return self._loader(self.train_dataset, True)
 
     def val_dataloader(self):
@@ -199,7 +220,7 @@ class Trainer:
         self._periodic: List = []  # paths
 
     def _save(self, lmodel, opt, epoch, val_acc):
-        if not self.dir:
+        if not self.dir or _rank() != 0:   # replicas are identical: rank 0 writes
             return None
         os.makedirs(self.dir, exist_ok=True)
         path = os.path.join(self.dir, f"checkpoint_{self.train_id}_epoch={epoch:02d}_val_acc={val_acc:.4f}.ckpt")
@@ -207,20 +228,25 @@ class Trainer:
         return path
 
     def _evaluate(self, lmodel, loader, data, kind):
+        """sample-weighted means over the WHOLE split: sums stay on the device (no per-batch host sync) and are all-reduced
+        over the ranks' shards once at the end"""
         lmodel.eval()
-        tot_loss = tot_acc = 0.0
-        n = 0
+        tot = torch.zeros(3, dtype=torch.float64, device=self.device)   # sum loss*n, sum acc*n, n
         with torch.no_grad():
             for i, batch in enumerate(loader):
                 b = data.on_device(batch, "eval", self.device)
+                nb = len(b[1])
                 if kind == "val":
                     loss, acc = lmodel.validation_step(b, i)
-                    tot_loss += float(loss) * len(b[1])
+                    tot[0] += loss.detach().double() * nb
                 else:
                     acc = lmodel.test_step(b, i)
-                tot_acc += float(acc) * len(b[1])
-                n += len(b[1])
-        return (tot_loss / max(n, 1), tot_acc / max(n, 1))
+                tot[1] += acc.detach().double() * nb
+                tot[2] += nb
+        if _world() > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        tot_loss, tot_acc, n = (float(v) for v in tot.cpu())
+        return (tot_loss / max(n, 1.0), tot_acc / max(n, 1.0))
 
     def fit(self, lmodel, datamodule, ckpt_path: Optional[str] = None):
         lmodel.to(self.device)
@@ -239,20 +265,27 @@ class Trainer:
         best, bad = -1.0, 0
         for epoch in range(start, self.max_epochs):
             lmodel.train()
-            run, nb = 0.0, 0
-            for i, batch in enumerate(datamodule.train_dataloader()):
+            run = torch.zeros(2, dtype=torch.float64, device=self.device)   # sum of step losses, steps: read ONCE per epoch
+            loader = datamodule.train_dataloader()
+            if hasattr(datamodule, "set_epoch"):
+                datamodule.set_epoch(epoch)
+            for i, batch in enumerate(loader):
                 opt.zero_grad()
                 loss = lmodel.training_step(datamodule.on_device(batch, "train", self.device), i)
                 (loss * (sync.grad_scale if sync else 1.0)).backward()
                 if sync:
                     sync.wait()
                 opt.step()
-                run += float(loss.detach())
-                nb += 1
+                run[0] += loss.detach().double()
+                run[1] += 1
+            if _world() > 1:
+                dist.all_reduce(run, op=dist.ReduceOp.SUM)
+            run_loss, nb = (float(v) for v in run.cpu())
             val_loss, val_acc = self._evaluate(lmodel, datamodule.val_dataloader(), datamodule, "val")
-            rec = dict(epoch=epoch, train_loss=run / max(nb, 1), val_loss=val_loss, val_acc=val_acc)
+            rec = dict(epoch=epoch, train_loss=run_loss / max(nb, 1.0), val_loss=val_loss, val_acc=val_acc)
             self.history.append(rec)
-            self.log(f"epoch {epoch}: train_loss {rec['train_loss']:.4f} val_loss {val_loss:.4f} val_acc {val_acc:.4f}")
+            if _rank() == 0:
+                self.log(f"epoch {epoch}: train_loss {rec['train_loss']:.4f} val_loss {val_loss:.4f} val_acc {val_acc:.4f}")
             # ModelCheckpoint(monitor='val_acc', mode='max', save_top_k=3)
             if self.dir and (len(self._top) < self.save_top_k or val_acc > min(a for a, _ in self._top)):
                 self._top.append((val_acc, self._save(lmodel, opt, epoch, val_acc)))
@@ -284,7 +317,8 @@ class Trainer:
             lmodel.load_state_dict(torch.load(ckpt_path, map_location=self.device, weights_only=False)["state_dict"])
         datamodule.setup('test')
         _, acc = self._evaluate(lmodel, datamodule.test_dataloader(), datamodule, "test")
-        self.log(f"test_acc {acc:.4f}")
+        if _rank() == 0:
+            self.log(f"test_acc {acc:.4f}")
         return acc
 
 

@@ -51,10 +51,19 @@ class VitEngine:
         self.grads: Optional[torch.Tensor] = None
         self.w16: Optional[torch.Tensor] = None
         self.wT16: Optional[torch.Tensor] = None
-        self._ws: "OrderedDict[int, Tuple[torch.Tensor, _capi.TicVitState, _capi.TicVitLayout]]" = OrderedDict()
+        self._ws: "OrderedDict[Tuple[int, int], Tuple[torch.Tensor, _capi.TicVitState, _capi.TicVitLayout]]" = OrderedDict()
         self._weights_version = -1
         self._w16_fresh = False
         self._cur_B = None
+        # extra version source: the module's Parameters keep their OWN version counters once `p.data` has been re-pointed
+        # at a new flat buffer (`.to()`), so in-place updates by stock torch optimizers never show in `params._version`
+        self.version_probe: Optional[Callable[[], int]] = None
+        # saved activations live in `live_graphs` workspaces per batch size, used round-robin; each forward stamps its
+        # workspace with a generation that backward checks (a stale stamp would mean silently wrong gradients)
+        self.live_graphs = 1
+        self._gen = 0
+        self._slot_gen: Dict[Tuple[int, int], int] = {}
+        self._slot_next: Dict[int, int] = {}
 
     # ---- layout ------------------------------------------------------------------------------------
     def _dims(self, B: int) -> _capi.TicVitDims:
@@ -122,6 +131,7 @@ class VitEngine:
         self.grads = None if self.grads is None else self.grads.to(device)
         self.w16 = self.wT16 = None
         self._ws.clear()
+        self._slot_gen.clear()
         self._weights_version = -1
         self.device = device
 
@@ -135,19 +145,22 @@ class VitEngine:
             self.wT16 = torch.empty(self.lay.t_total, dtype=torch.bfloat16, device=dev)
             self._weights_version = -1
 
-    def _state(self, B: int):
+    def _state(self, B: int, slot: int = 0):
         self._ensure_device_state()
-        if B in self._ws:
-            self._ws.move_to_end(B)
-            return self._ws[B]
+        key = (B, slot)
+        if key in self._ws:
+            self._ws.move_to_end(key)
+            return self._ws[key]
         lay = self._layout(B)
-        while len(self._ws) >= 2:   # keep at most two batch sizes resident (train batch + tail / eval batch)
-            self._ws.popitem(last=False)
+        # keep at most two batch sizes resident (train batch + tail / eval batch), `live_graphs` workspaces each
+        while len(self._ws) >= 2 * max(1, self.live_graphs):
+            old, _ = self._ws.popitem(last=False)
+            self._slot_gen.pop(old, None)   # a backward that still needs it will raise (stale stamp), not read garbage
         ws = torch.empty(lay.ws_bytes, dtype=torch.uint8, device=self.params.device)
         st = _capi.TicVitState(self._dims(B), self.params.data_ptr(), self.grads.data_ptr(), self.w16.data_ptr(),
                                self.wT16.data_ptr(), ws.data_ptr())
-        self._ws[B] = (ws, st, lay)
-        return self._ws[B]
+        self._ws[key] = (ws, st, lay)
+        return self._ws[key]
 
     # ---- phases --------------------------------------------------------------------------------------
     def mark_weights_dirty(self, w16_fresh: bool = False) -> None:
@@ -158,29 +171,53 @@ class VitEngine:
     def refresh_weights_if_needed(self) -> None:
         """bf16 operand copies follow the fp32 master weights (torch bumps `_version` on every in-place
         update of any view, e.g. optimizer.step(); our own AdamW keeps w16 fresh and calls mark_*)."""
-        v = self.params._version
+        v = self._version()
         if v != self._weights_version:
             # any state works (dims.B is irrelevant for weights); make sure one exists
             _, st, _ = self._state(self._cur_B or 1)
             self.backend.call("tic_vit_refresh_weights", ctypes.byref(st), 1 if self._w16_fresh else 0, self.backend.stream())
-            self._weights_version = self.params._version
+            self._weights_version = self._version()
             self._w16_fresh = False
 
+    def _version(self) -> int:
+        v = self.params._version
+        return v if self.version_probe is None else v + self.version_probe()
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.forward_stamped(x)[0]
+
+    def forward_stamped(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
+        """-> (logits, stamp).  `stamp` = (B, workspace slot, generation) identifies the saved activations this forward
+        left behind; pass it to `backward` to have a later overwrite (another forward at the same batch size, an
+        eviction) detected instead of differentiated."""
         B = x.shape[0]
         self._cur_B = B
-        _, st, _ = self._state(B)
+        slot = self._slot_next.get(B, 0) % max(1, self.live_graphs)
+        self._slot_next[B] = slot + 1
+        _, st, _ = self._state(B, slot)
         self.refresh_weights_if_needed()
         logits = torch.empty(B, self.C, dtype=torch.float32, device=x.device)
         self.backend.call("tic_vit_forward", ctypes.byref(st), x.data_ptr(), logits.data_ptr(), self.backend.stream())
-        return logits
+        self._gen += 1
+        self._slot_gen[(B, slot)] = self._gen
+        return logits, (B, slot, self._gen)
 
     def backward(self, dlogits: torch.Tensor, bucket_hook: Optional[Callable[[str, int, int], None]] = None,
-                 head_only: bool = False) -> None:
+                 head_only: bool = False, stamp: Optional[Tuple[int, int, int]] = None) -> None:
         """Accumulates into self.grads.  bucket_hook(name, start, end) fires as each bucket's gradients are
         complete (enqueued) so a data-parallel wrapper can all-reduce it while earlier layers still run."""
         B = dlogits.shape[0]
-        _, st, _ = self._state(B)
+        if stamp is None:   # fused step: the forward that just ran
+            slot = (self._slot_next.get(B, 1) - 1) % max(1, self.live_graphs)
+        else:
+            slot = stamp[1]
+            if stamp[0] != B or self._slot_gen.get((B, slot)) != stamp[2]:
+                raise RuntimeError(
+                    "TIC ViT backward: the activations saved by this forward are gone -- another forward at batch size "
+                    f"{stamp[0]} (or a third batch size) ran before this backward and re-used its workspace. Run each "
+                    "backward before the next forward at the same batch size, or set `model._engine.live_graphs = k` to keep "
+                    "k graphs per batch size alive.")
+        _, st, _ = self._state(B, slot)
         s = self.backend.stream()
         bk = self.buckets()
         self.backend.call("tic_vit_backward_head", ctypes.byref(st), dlogits.data_ptr(), s)
@@ -198,7 +235,7 @@ class VitEngine:
 
     def activation(self, B: int, name: str, layer: Optional[int] = None) -> Tuple[int, int]:
         """(byte offset, byte stride-to-next-layer) of a saved activation inside the workspace (tests)."""
-        _, _, lay = self._state(B)
+        _, _, lay = self._state(B, (self._slot_next.get(B, 1) - 1) % max(1, self.live_graphs))
         off = getattr(lay, name)
         if layer is not None and name in ("a1", "mean1", "rstd1", "qkv", "lse", "o", "hmid", "a2", "mean2", "rstd2", "u", "g"):
             off += lay.layer_ws + layer * lay.layer_ws_stride
