@@ -2,17 +2,27 @@
 """Headline benchmark: images/sec of the ViT-L/16 224 px bf16 fine-tune step (fwd + CE + bwd + gradient
 all-reduce + AdamW) on synthetic 3x224x224 batches, weak scaling over N MI355X (one process per GPU).
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (torch.distributed.run child)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline`: whole-step algorithmic FLOPs (369.32 GFLOP per
-image for ViT-L/16 C=120, train = 3 x fwd) / measured time vs the dense bf16 MFMA peak (2.5 PFLOP/s),
-plus the dominant kernel (gemm_nt, fc1 shape) timed on its own with HIP events on its launch stream.
-`cpu_baseline`: the CPU oracle (oracle/vit_oracle.py, a port) timed on this box's host cores, N=1 only.
+Rank 0 prints ONE JSON line.
+  roofline      dominant kernel (grouped dW GEMM of one block): algorithmic FLOPs per launch / its average launch duration,
+                measured LIVE with HIP events on its launch stream inside the timed steps; plus the whole step
+                (img/s x 369.32 GFLOP per image) against the dense bf16 MFMA peak (2.5 PFLOP/s)
+  parity        SURVEY 8d: the CPU oracle and the HIP model get the SAME seeded weights and the same B=4 batch in this run;
+                max |dlogits|, relative loss difference, top-1 / top-5 agreement
+  cpu_baseline  the CPU oracle (oracle/vit_oracle.py, a port) timed on this box's host cores, N = 1 only:
+                3 warm-up + 5 timed steps, median; headline config in fp32, `also` = bf16-autocast and BASELINE config 1
+  sweep         per-GPU batch {32, 64, 128} (the sizes the reference fine-tunes at), outside the headline timed region
+  dp            N > 1: RCCL rank count actually observed, per-rank ms/step min / max, all-reduce time not hidden by backward
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -46,36 +56,112 @@ def host_cores():
     return max(1, min(n, 16))   # a 1-GPU box owns a 16-core share
 
 
-def cpu_baseline(model_key, C, seconds_budget=20.0):
-    """oracle fwd+bwd+AdamW (fp32, B=4) on the host cores: a reported baseline, not a target"""
+# ---- CPU side: oracle timing + the in-run parity reference -----------------------------------------------------------------------
+def _oracle_spec(model_key, C):
     from oracle import vit_oracle as vo
     m = MODELS[model_key]
-    cores = host_cores()
-    torch.set_num_threads(cores)
-    spec = vo.ViTSpec(hidden=m["hidden"], layers=m["layers"], heads=m["heads"], mlp=m["mlp"], num_labels=C)
-    params = vo.init_params(spec, seed=0)
-    B = 4
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(B, 3, 224, 224, generator=g)
-    y = torch.randint(0, C, (B,), generator=g)
+    return vo.ViTSpec(hidden=m["hidden"], layers=m["layers"], heads=m["heads"], mlp=m["mlp"], num_labels=C)
+
+
+def _time_oracle(model_key, C, params, x, y, autocast, warm=3, timed=5, budget_s=40.0):
+    """fwd + bwd + AdamW of the oracle on the host cores; median step time of `timed` steps after `warm` warm-ups (both cut
+    short, never below 1 + 2, if the budget runs out: the default bench run must finish in minutes)"""
+    from oracle import vit_oracle as vo
+    spec = _oracle_spec(model_key, C)
+    params = {k: v.clone() for k, v in params.items()}
     mom = {k: torch.zeros_like(v) for k, v in params.items()}
     var = {k: torch.zeros_like(v) for k, v in params.items()}
+    first = {}
 
     def step(i):
-        _, _, grads = vo.loss_and_grads(params, x, y, spec)
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            logits, loss, grads = vo.loss_and_grads(params, x, y, spec)
+        if not first:
+            first.update(logits=logits.float(), loss=float(loss))
         for k in params:
-            vo.adamw_step(params[k], grads[k], mom[k], var[k], i, lr=1e-5, wd=0.01)
+            vo.adamw_step(params[k], grads[k].float(), mom[k], var[k], i, lr=1e-5, wd=0.01)
 
+    t_start = time.perf_counter()
+    i = 0
+    for _ in range(warm):
+        i += 1
+        step(i)
+        if time.perf_counter() - t_start > 0.4 * budget_s:
+            break
+    warm_done = i
+    ts = []
+    for _ in range(timed):
+        i += 1
+        t0 = time.perf_counter()
+        step(i)
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s and len(ts) >= 2:
+            break
+    return statistics.median(ts), warm_done, len(ts), first
+
+
+def cpu_legs(model_key, C, params, x4, y4):
+    """-> (cpu_baseline object, fp32 oracle logits / loss of the parity batch at the initial weights)"""
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    B = x4.shape[0]
     print(f"[bench] cpu baseline on {cores} threads ...", file=sys.stderr, flush=True)
-    step(1)   # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < 1 or (time.perf_counter() - t0 < seconds_budget and n < 6):
-        n += 1
-        step(n + 1)
-    dt = time.perf_counter() - t0
-    return dict(value=round(B * n / dt, 3), unit="images/sec", cores=cores, kind="port",
-                sample=f"{n} steps of fwd+bwd+AdamW, ViT-{model_key} C={C} B={B} fp32, torch CPU ops via oracle/vit_oracle.py")
+    med, w, n, first = _time_oracle(model_key, C, params, x4, y4, autocast=False)
+    base = dict(value=round(B / med, 3), unit="images/sec", cores=cores, kind="port",
+                sample=f"median of {n} timed steps after {w} warm-up: fwd+bwd+AdamW, ViT-{model_key} C={C} B={B} fp32, torch CPU ops via oracle/vit_oracle.py")
+    also = []
+    med, w, n, _ = _time_oracle(model_key, C, params, x4, y4, autocast=True, budget_s=30.0)
+    also.append(dict(value=round(B / med, 3), unit="images/sec", cores=cores, kind="port",
+                     sample=f"same, under torch.autocast('cpu', bfloat16); median of {n} after {w} warm-up"))
+    # BASELINE config 1: ViT-Base/16, 10 classes, batch 4 on the CPU
+    from oracle import vit_oracle as vo
+    pb = vo.init_params(_oracle_spec("base", 10), seed=0)
+    g = torch.Generator().manual_seed(1234)
+    xb = torch.randn(4, 3, 224, 224, generator=g)
+    yb = torch.randint(0, 10, (4,), generator=g)
+    for ac in (False, True):
+        med, w, n, _ = _time_oracle("base", 10, pb, xb, yb, autocast=ac, budget_s=15.0)
+        also.append(dict(value=round(4 / med, 3), unit="images/sec", cores=cores, kind="port",
+                         sample=f"BASELINE config 1: ViT-base C=10 B=4 {'bf16-autocast' if ac else 'fp32'}; median of {n} after {w} warm-up"))
+    base["also"] = also
+    return base, first
+
+
+def parity_block(hip_logits, hip_loss, ref_logits, ref_loss, y):
+    """same weights, same batch: HIP (bf16 GEMMs) vs the fp32 CPU oracle"""
+    d = (hip_logits - ref_logits).abs().max().item()
+    top1 = (hip_logits.argmax(-1) == ref_logits.argmax(-1)).float().mean().item()
+    k = min(5, ref_logits.shape[1])
+    t5h, t5r = hip_logits.topk(k, -1).indices, ref_logits.topk(k, -1).indices
+    top5 = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(t5h, t5r)) / float(k * len(t5h))
+    # rows whose fp32 top-1 margin is larger than the logit difference: there a disagreement would be an error, not rounding
+    srt = ref_logits.sort(-1, descending=True).values
+    decidable = (srt[:, 0] - srt[:, 1]) > 2 * d
+    agree_dec = bool((hip_logits.argmax(-1) == ref_logits.argmax(-1))[decidable].all()) if decidable.any() else True
+    return dict(batch=int(ref_logits.shape[0]), max_abs_dlogits=round(d, 6), logit_scale=round(ref_logits.abs().max().item(), 4),
+                loss_hip=round(hip_loss, 6), loss_cpu=round(ref_loss, 6), loss_rel=round(abs(hip_loss - ref_loss) / max(abs(ref_loss), 1e-12), 6),
+                top1_match=round(top1, 4), top5_match=round(top5, 4), top1_decidable_rows=int(decidable.sum()), top1_match_on_decidable=agree_dec,
+                tolerance="logits atol 2e-2 + rtol 2e-2, loss rtol 1e-2 (tests/test_gpu_model.py)")
+
+
+# ---- launching N ranks ourselves ------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (a torch.distributed.run child) BEFORE this
+    process makes any GPU call, relay their output, exit with their code.  Nothing here touches HIP."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    print(f"[bench] starting {n} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    rc = subprocess.run(cmd, env=env).returncode
+    raise SystemExit(rc)
 
 
 def main():
@@ -85,80 +171,123 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=332,
                     help="images per GPU per step (weak scaling). 332 x 197 tokens = 256 row tiles of 256: with 4 / 12 / 16 column tiles "
-                         "every big GEMM launches a whole multiple of the 256 CUs (83 / 166 / 249 are the next such sizes down; "
-                         "measured 2115 / 2184 / 2214 img/s at 166 / 249 / 332)")
+                         "every big GEMM launches a whole multiple of the 256 CUs; the `sweep` list reports 32 / 64 / 128")
     ap.add_argument("--model", default="large", choices=list(MODELS))
     ap.add_argument("--classes", type=int, default=120)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--sweep", default="32,64,128", help="per-GPU batch sizes reported beside the headline")
     ap.add_argument("--autograd", action="store_true", help="drive the step through torch autograd + F.cross_entropy (plugin surface) instead of the fused step")
     ap.add_argument("--aug", action="store_true", help="BASELINE config 3: include the on-GPU augmentation (uint8 256x256 thumbnails -> crop/flip/jitter/gray/erase/normalise) and MixUp/CutMix (soft labels) in every timed step")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="launch rehearsal on a 1-GPU box: all N ranks share device 0 and the collectives go over gloo (RCCL refuses a "
+                         "duplicate device). Exercises the self-launch and the DP code path; the number it prints is not a result")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the TIC hot path has no CPU fallback")
+    if not args.rehearse_one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPUs are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_ranks = 1
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())   # the rank count the collective library really summed over
+        if rccl_ranks != world:
+            raise SystemExit(f"bench.py: all_reduce of ones over {world} ranks returned {rccl_ranks}")
 
     from touhouimageclassification_amd.ViT.model import ViT
     from touhouimageclassification_amd.dist import BucketedGradSync
     from touhouimageclassification_amd.optim import FusedAdamW
     from touhouimageclassification_amd.step import fused_train_step
-    from touhouimageclassification_amd import ops
+    from touhouimageclassification_amd._lib import call as _tic_call
 
     m = MODELS[args.model]
     C, B = args.classes, args.batch
     torch.manual_seed(0)
     model = ViT(C, pretrained=False, model_name=m["name"])
     model.reset_parameters(seed=0)
+    init_params = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None   # CPU copy for the oracle
     model.to(dev)
     sync = BucketedGradSync(model)
     sync.broadcast_parameters()
     opt = FusedAdamW(model, lr=1e-5, weight_decay=0.01)   # ntrain.py:256-257
     g = torch.Generator().manual_seed(1234 + rank)
-    x = torch.randn(B, 3, 224, 224, generator=g).to(dev)
-    y = torch.randint(0, C, (B,), generator=g).to(dev)
+    x_cpu = torch.randn(B, 3, 224, 224, generator=g)
+    y_cpu = torch.randint(0, C, (B,), generator=g)
+    x, y = x_cpu.to(dev), y_cpu.to(dev)
     if args.aug:
         from touhouimageclassification_amd.aug import CutMixOrMixUp, GpuAugment
         raw = torch.randint(0, 256, (B, 256, 256, 3), dtype=torch.uint8, generator=g).to(dev)   # dataset thumbnails are 256x256
         augment, mixer = GpuAugment("full", 224, seed=1 + rank), CutMixOrMixUp(C, seed=2 + rank)
 
-    def step():
-        if args.autograd:
-            opt.zero_grad()
-            loss = torch.nn.functional.cross_entropy(model(x).logits, y) * sync.grad_scale
-            loss.backward()
-            sync.wait()
-            opt.step()
-            return loss
-        if args.aug:
-            xa, ya = mixer(augment(raw), y)   # parameter sampling on the host, pixels on the GPU
-            return fused_train_step(model, opt, xa, ya, sync)[0]
-        return fused_train_step(model, opt, x, y, sync)[0]
+    # ---- in-run parity: HIP forward + CE of the first 4 images at the initial weights (the oracle runs on the same later) ----
+    hip4 = None
+    if rank == 0:
+        from touhouimageclassification_amd import ops
+        with torch.no_grad():
+            lg = model(x[:4]).logits
+            ls, _ = ops.softmax_xent(lg, y[:4], want_grad=False)
+        hip4 = (lg.float().cpu(), float(ls))
 
+    def make_step(xb, yb):
+        def step():
+            if args.autograd:
+                opt.zero_grad()
+                loss = torch.nn.functional.cross_entropy(model(xb).logits, yb) * sync.grad_scale
+                loss.backward()
+                sync.wait()
+                opt.step()
+                return loss
+            if args.aug:
+                xa, ya = mixer(augment(raw[:xb.shape[0]]), yb)   # parameter sampling on the host, pixels on the GPU
+                return fused_train_step(model, opt, xa, ya, sync)[0]
+            return fused_train_step(model, opt, xb, yb, sync)[0]
+        return step
+
+    def timed(step, steps, warmup):
+        """contract: W untimed steps, barrier + synchronize, EXACTLY K steps, synchronize + barrier; MAX over ranks"""
+        for _ in range(warmup):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt, mine, -mine], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return tt[0].item(), tt[1].item(), -tt[2].item(), loss
+
+    step = make_step(x, y)
     if rank == 0:
         print(f"[bench] ViT-{args.model} B={B}/GPU world={world}: warm-up", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    from touhouimageclassification_amd._lib import call as _tic_call
     if rank == 0:
         _tic_call("tic_kernel_timer_enable", 1)   # HIP events around every grouped-dW launch of the timed steps, on their stream
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    dt, slowest, fastest, loss = timed(step, args.steps, 0)
     dw_launches, dw_total_ms = 0, 0.0
     if rank == 0:
         import ctypes as _ct
@@ -166,37 +295,62 @@ def main():
         _tic_call("tic_kernel_timer_read", _ct.byref(n_), _ct.byref(ms_))
         _tic_call("tic_kernel_timer_enable", 0)
         dw_launches, dw_total_ms = n_.value, ms_.value
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = tt.item()
     loss_v = float(loss)
     if rank == 0:
         print(f"[bench] {args.steps} steps in {dt:.3f}s = {world * B * args.steps / dt:.1f} img/s, loss {loss_v:.4f}", file=sys.stderr, flush=True)
 
-    # dominant kernel of the step (23 % of it): the grouped weight-gradient GEMM of one transformer block,
+    fl = train_flops_per_image(m, C)
+    # ---- N > 1: how much of the all-reduce is NOT hidden behind backward (same steps with the bucket hook off) ------------------
+    dp = None
+    if world > 1:
+        hook = model._bucket_hook
+        model.register_bucket_hook(None)
+        dt_off, _, _, _ = timed(step, max(5, args.steps // 2), 2)
+        model.register_bucket_hook(hook)
+        sync.broadcast_parameters()   # the unsynchronised steps let the replicas drift: re-align them
+        ms_on, ms_off = 1e3 * dt / args.steps, 1e3 * dt_off / max(5, args.steps // 2)
+        dp = dict(collective="gloo (one-GPU rehearsal)" if args.rehearse_one_gpu else "RCCL all_reduce(SUM) per bucket, side stream",
+                  ranks_observed=rccl_ranks, ms_per_step_slowest_rank=round(1e3 * slowest / args.steps, 3),
+                  ms_per_step_fastest_rank=round(1e3 * fastest / args.steps, 3), ms_per_step_no_allreduce=round(ms_off, 3),
+                  allreduce_exposed_ms=round(ms_on - ms_off, 3), grad_bytes_per_step=4 * model._engine.lay.n_params,
+                  buckets=len(model._engine.buckets()))
+
+    # ---- realistic per-GPU batches (outside the headline timed region) --------------------------------------------------------
+    sweep = []
+    if not args.no_sweep:
+        for bs in [int(s) for s in args.sweep.split(",") if s]:
+            if bs >= B:
+                continue
+            st = make_step(x[:bs].contiguous(), y[:bs].contiguous())
+            k = max(5, min(args.steps, 10))
+            d, _, _, _ = timed(st, k, 3)
+            ips = world * bs * k / d
+            sweep.append(dict(per_gpu_batch=bs, value=round(ips, 1), ms_per_step=round(1e3 * d / k, 3), steps=k,
+                              step_frac=round(ips * fl / world / 1e12 / PEAK_BF16_TFLOPS, 4)))
+            if rank == 0:
+                print(f"[bench] sweep B={bs}: {ips:.1f} img/s", file=sys.stderr, flush=True)
+
+    # dominant kernel of the step (22 % of it): the grouped weight-gradient GEMM of one transformer block,
     # dW_g[N,K] += dY_g^T . X_g for the 4 Linear layers, ONE launch per block.  Its duration is measured LIVE, inside the timed
     # region: the library records HIP events on the launch stream around each of its launches (tic_kernel_timer_*), so
     # ms_per_launch is the average over the L x steps launches the timed steps made (the same launches a
     # `rocprofv3 --kernel-trace --stats -- python3 bench.py` summary averages).  Algorithmic FLOPs per launch = 2 M (4 D^2 + 2 D F).
-    dom = None
     if rank == 0:
         M, D, F = B * 197, m["hidden"], m["mlp"]
         shapes = [(D, F), (F, D), (D, D), (3 * D, D)]
         kflops = 2.0 * M * sum(n * k for n, k in shapes)
         ms = dw_total_ms / max(dw_launches, 1)
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section); only valid for
+        # the kernel source it was measured on: the record carries the hash of csrc/gemm_tn256.h and goes stale (null) with any edit
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+        tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tf):
             rec = json.load(open(tf))
-            if rec.get("M") == M and rec.get("hidden") == D:
+            src = os.path.join(ROOT, "touhouimageclassification_amd", "csrc", "gemm_tn256.h")
+            if rec.get("M") == M and rec.get("hidden") == D and rec.get("src_sha256") == hashlib.sha256(open(src, "rb").read()).hexdigest():
                 traffic = rec["hbm_bytes_per_launch"]
-        dom = dict(kernel="gemm_tn256_streamk_kernel (grouped dW of one block)", M=M, flops_per_launch=kflops, ms=round(ms, 4), launches=dw_launches,
-                   tflops=round(kflops / (ms * 1e-3) / 1e12, 1) if dw_launches else 0.0, traffic=traffic)
-
-    if rank == 0:
+        tfl = round(kflops / (ms * 1e-3) / 1e12, 1) if dw_launches else 0.0
         ips = world * B * args.steps / dt
-        fl = train_flops_per_image(m, C)
         achieved = ips * fl / world / 1e12
         out = {
             "metric": f"images/sec ViT-{'L' if args.model == 'large' else 'B'}/16 224px bf16 fine-tune",
@@ -208,17 +362,35 @@ def main():
                        "optimizer": "AdamW lr=1e-5 wd=0.01 (fused, fp32 master weights)", "step_driver": "autograd" if args.autograd else "fused", "gpu_augmentation": bool(args.aug)},
             "loss": round(loss_v, 5),
             # dominant kernel (contract): algorithmic FLOPs per launch / its average launch duration (HIP events, live)
-            "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": dom["traffic"],
-                         "kernel": dom["kernel"], "M": dom["M"], "flops_per_launch": dom["flops_per_launch"], "ms_per_launch": dom["ms"],
-                         "launches_timed": dom["launches"],
+            "roofline": {"bound": "mfma", "achieved": tfl, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tfl / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "gemm_tn256_streamk_kernel (grouped dW of one block)", "M": M, "flops_per_launch": kflops, "ms_per_launch": round(ms, 4),
+                         "launches_timed": dw_launches,
                          # whole step: img/s x 369.32 GFLOP/img / n_gpus vs the same peak
                          "step_achieved": round(achieved, 1), "step_frac": round(achieved / PEAK_BF16_TFLOPS, 4), "flops_per_image": fl},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model, C)
+        if args.rehearse_one_gpu:
+            out["rehearsal"] = "all ranks on ONE GPU over gloo: launch-path check only, not a result"
+        if dp:
+            out["dp"] = dp
+        if sweep:
+            out["sweep"] = sweep
+        if not args.no_cpu_baseline:
+            if world == 1:
+                base, first = cpu_legs(args.model, C, init_params, x_cpu[:4], y_cpu[:4])
+                out["cpu_baseline"] = base
+                ref_logits, ref_loss = first["logits"], first["loss"]
+            else:   # N > 1: no CPU timing (contract), but the parity reference still runs (one oracle forward)
+                from oracle import vit_oracle as vo
+                torch.set_num_threads(max(1, host_cores() // world))
+                spec = _oracle_spec(args.model, C)
+                with torch.no_grad():
+                    ref_logits = vo.forward(init_params, x_cpu[:4], spec)
+                    ref_loss = float(vo.cross_entropy(ref_logits, y_cpu[:4]))
+            out["parity"] = parity_block(hip4[0], hip4[1], ref_logits, ref_loss, y_cpu[:4])
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -242,6 +242,28 @@ int tic_vit_backward_head(const TicVitState* st, const float* dlogits, tic_strea
 int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stream_t stream);
 int tic_vit_backward_embed(const TicVitState* st, tic_stream_t stream);
 
+/* ---- mixture of ViT experts: gate / combine / loss arithmetic (BASELINE config 5) ------------------------------------
+ * The expert and gate networks are ViT classifiers (tic_vit_*); these are the small ops between them.
+ * Expert outputs are EXPERT-major: expert_out[E][B][C] fp32 (each expert, or each peer rank, owns one contiguous slab). */
+/* gate (TIC/ResMoE/model.py:33-38 + the scatter at :53-54): z = logits + noise_scale * noise (noise may be NULL: eval mode);
+ * top-K by value (ties: lowest expert index); softmax over the K selected values; gate_w[B,E] = those weights scattered, 0
+ * elsewhere; topk_idx[B,K] int64 and topk_w[B,K] in descending order of z.  1 <= K <= 8, E <= 64. */
+int tic_moe_gate(const float* logits, const float* noise, float noise_scale, float* gate_w, int64_t* topk_idx, float* topk_w,
+                 int B, int E, int K, tic_stream_t stream);
+/* dlogits[B,E] = gate_w (.) (d_gate_w - <gate_w, d_gate_w>): softmax Jacobian on the selected experts, 0 elsewhere */
+int tic_moe_gate_bwd(const float* gate_w, const float* d_gate_w, float* dlogits, int B, int E, tic_stream_t stream);
+/* out[B,C] = sum_e gate_w[b,e] expert_out[e,b,:]      (torch.bmm(gate_weights.unsqueeze(1), expert_outputs), model.py:56-57) */
+int tic_moe_combine(const float* expert_out, const float* gate_w, float* out, int B, int E, int C, tic_stream_t stream);
+/* d_expert_out[e,b,:] = gate_w[b,e] dout[b,:] ; d_gate_w[b,e] = <expert_out[e,b,:], dout[b,:]> */
+int tic_moe_combine_bwd(const float* expert_out, const float* gate_w, const float* dout, float* d_expert_out, float* d_gate_w,
+                        int B, int E, int C, tic_stream_t stream);
+/* total_loss (TIC/ResMoE/train.py:21-36): loss3[0] = a_ce CE(z,t) + b_rce RCE(z,t) + a_balance BAL(w), loss3[1] = the first two
+ * terms ("classification loss"), loss3[2] = BAL(w) unweighted.  RCE = -mean_b sum_c softmax(z)_c log_softmax(t)_c (log_softmax
+ * of the TARGETS, as the reference writes it); BAL = mean_b <w[b,:], mean_b' w[b',:]>.  targets[B,C] fp32 (one-hot or soft).
+ * dlogits[B,C] / d_gate_w[B,E] receive d loss3[0] (either may be NULL); gate_w NULL skips the balance term.  loss3 is overwritten. */
+int tic_moe_loss(const float* logits, const float* targets, const float* gate_w, float* loss3, float* dlogits, float* d_gate_w,
+                 int B, int C, int E, float a_ce, float b_rce, float a_balance, tic_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -354,3 +354,60 @@ def check_fused_bias_gradients(env):
     torch.testing.assert_close(dbias3[:2 * Dm], 0.25 + dbias[:2 * Dm], atol=1e-3, rtol=1e-4)
     assert torch.equal(dbias3[2 * Dm:], torch.full((Dm,), 0.25, device=dev))
     torch.testing.assert_close(do.float().sum(0), dbias[2 * Dm:], atol=0.02 * float(do.float().abs().sum(0).max()) + 0.05, rtol=0.02)
+
+
+def check_moe_ops(env, B=7, E=8, K=2, C=120):
+    """gate / combine / loss kernels (csrc/moe.h) and their backward launches vs oracle/moe_oracle.py + autograd"""
+    from oracle import moe_oracle as mo
+    rnd, call, dev = env.rnd, env.call, env.dev
+    logits, noise = rnd(B, E), rnd(B, E)
+    if E >= 6:                           # a tie between the two largest scores of row 0: both are selected, order is the kernel's
+        logits[0, 3] = logits[0, 5] = 5.0   # (lowest index first); rows 1.. have distinct values
+        noise[0, 3] = noise[0, 5]
+    gw = torch.empty(B, E, device=dev)
+    idx = torch.empty(B, K, dtype=torch.int64, device=dev)
+    tw = torch.empty(B, K, device=dev)
+    call("tic_moe_gate", ptr(logits), ptr(noise), 0.01, ptr(gw), ptr(idx), ptr(tw), B, E, K, None)
+    lr = logits.cpu().clone().requires_grad_(True)
+    rw, ri = mo.gate(lr, noise.cpu(), K)
+    rg = mo.scatter(rw, ri, E)
+    assert torch.equal(idx.cpu()[1:], ri[1:]) and set(idx.cpu()[0].tolist()) == set(ri[0].tolist())
+    torch.testing.assert_close(tw.cpu()[1:], rw.detach()[1:], atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(gw.cpu(), rg.detach(), atol=1e-6, rtol=1e-5)
+    dgw = rnd(B, E)
+    rg.backward(dgw.cpu())
+    dl = torch.empty(B, E, device=dev)
+    call("tic_moe_gate_bwd", ptr(gw), ptr(dgw), ptr(dl), B, E, None)
+    torch.testing.assert_close(dl.cpu(), lr.grad, atol=1e-6, rtol=1e-4)
+    # eval mode: no noise pointer
+    call("tic_moe_gate", ptr(logits), None, 0.01, ptr(gw), ptr(idx), ptr(tw), B, E, K, None)
+    torch.testing.assert_close(gw.cpu()[1:], mo.scatter(*mo.gate(logits.cpu(), None, K), E)[1:], atol=1e-6, rtol=1e-5)
+    # combine
+    X = rnd(E, B, C)
+    w = torch.softmax(rnd(B, E), -1) * (rnd(B, E) > 0)
+    out = torch.empty(B, C, device=dev)
+    call("tic_moe_combine", ptr(X), ptr(w), ptr(out), B, E, C, None)
+    xr, wr = X.cpu().clone().requires_grad_(True), w.cpu().clone().requires_grad_(True)
+    ro = mo.combine(xr.permute(1, 0, 2), wr)
+    torch.testing.assert_close(out.cpu(), ro.detach(), atol=1e-5, rtol=1e-5)
+    dout = rnd(B, C)
+    ro.backward(dout.cpu())
+    dX, dw = torch.empty_like(X), torch.empty_like(w)
+    call("tic_moe_combine_bwd", ptr(X), ptr(w), ptr(dout), ptr(dX), ptr(dw), B, E, C, None)
+    torch.testing.assert_close(dX.cpu(), xr.grad, atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(dw.cpu(), wr.grad, atol=1e-5, rtol=1e-5)
+    # loss: one-hot and soft targets
+    for soft in (False, True):
+        z = rnd(B, C)
+        t = torch.softmax(rnd(B, C), -1) if soft else torch.nn.functional.one_hot(torch.randint(0, C, (B,), generator=env.gen), C).float().to(dev)
+        g = torch.softmax(rnd(B, E), -1)
+        loss3, dz, dg = torch.empty(3, device=dev), torch.empty(B, C, device=dev), torch.empty(B, E, device=dev)
+        call("tic_moe_loss", ptr(z), ptr(t), ptr(g), ptr(loss3), ptr(dz), ptr(dg), B, C, E, 0.1, 1.0, 0.5, None)
+        zr, gr = z.cpu().clone().requires_grad_(True), g.cpu().clone().requires_grad_(True)
+        ref = mo.total_loss(zr, t.cpu(), gr)
+        ref.backward()
+        torch.testing.assert_close(loss3.cpu()[0], ref.detach(), atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(loss3.cpu()[1], mo.symmetric_cross_entropy(z.cpu(), t.cpu()), atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(loss3.cpu()[2], mo.load_balance_loss(g.cpu()), atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(dz.cpu(), zr.grad, atol=1e-6, rtol=1e-4)
+        torch.testing.assert_close(dg.cpu(), gr.grad, atol=1e-7, rtol=1e-4)

@@ -33,13 +33,30 @@ def test_dense_moe_step_and_losses():
     logits, gw, idx = m(x[:B])
     assert logits.shape == (B, C) and gw.shape == (B, E) and idx.shape == (B, 2)
     torch.testing.assert_close(gw.sum(1), torch.ones(B))
-    loss = mt.total_loss(logits, torch.nn.functional.one_hot(y[:B], C).float(), gw, idx)
+    tgt = torch.nn.functional.one_hot(y[:B], C).float()
+    loss = mt.total_loss(logits, tgt, gw, idx, backend=SimBackend())
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
-    # the combination is the documented one
-    eo = torch.stack([e(x[:B]).logits for e in m.experts], 1)
-    torch.testing.assert_close(logits, (gw.unsqueeze(-1) * eo).sum(1), atol=1e-5, rtol=1e-5)
-    assert abs(mt.load_balance_loss(gw, idx, E).item() - (gw @ gw.mean(0)).mean().item()) < 1e-6
+    # gate, combination and loss are the reference's arithmetic (oracle/moe_oracle.py restates it line for line)
+    from oracle import moe_oracle as mo
+    eo = torch.stack([e(x[:B]).logits for e in m.experts], 1).detach()
+    scores = m.gate.vit(x[:B]).logits.detach()
+    rw, ri = mo.gate(scores, None, 2)
+    assert torch.equal(idx, ri)
+    torch.testing.assert_close(gw.detach(), mo.scatter(rw, ri, E), atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(logits.detach(), mo.combine(eo, gw.detach()), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(loss.detach(), mo.total_loss(logits.detach(), tgt, gw.detach()), atol=1e-5, rtol=1e-5)
+    assert abs(mt.load_balance_loss(gw, idx, E).item() - mo.load_balance_loss(gw.detach()).item()) < 1e-6
+    # the reference-shaped gate call still returns (top-k weights, top-k indices)
+    tw, ti = m.gate(x[:B])
+    assert tw.shape == (B, 2) and torch.equal(ti, ri) and torch.allclose(tw.sum(1), torch.ones(B))
+
+
+def test_moe_kernels_match_oracle_in_the_simulator():
+    from tests import kernel_checks as kc
+    from tests.simlib import call
+    kc.check_moe_ops(kc.Env("cpu", call), B=5, E=8, K=2, C=70)
+    kc.check_moe_ops(kc.Env("cpu", call, seed=1), B=3, E=3, K=3, C=5)
 
 
 def _ep_worker(rank, world, port, out_dir):
@@ -55,7 +72,7 @@ def _ep_worker(rank, world, port, out_dir):
     x, y = _data()
     xs, ys = x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B]
     logits, gw, idx = ep(xs)
-    loss = mt.total_loss(logits, torch.nn.functional.one_hot(ys, C).float(), gw, idx) / world
+    loss = mt.total_loss(logits, torch.nn.functional.one_hot(ys, C).float(), gw, idx, backend=SimBackend()) / world
     loss.backward()
     ep.sync_gate_gradients()
     torch.save({"logits": logits.detach(), "expert_grad": dense.experts[rank].classifier.weight.grad.clone(),
@@ -76,7 +93,7 @@ def test_expert_parallel_matches_dense(tmp_path):
     logits, gw, idx = dense(x)
     # per-rank losses are means over the local batch; the EP run scaled each by 1/world
     loss = sum(mt.total_loss(logits[r * B:(r + 1) * B], torch.nn.functional.one_hot(y[r * B:(r + 1) * B], C).float(), gw[r * B:(r + 1) * B],
-                             idx[r * B:(r + 1) * B]) for r in range(E)) / E
+                             idx[r * B:(r + 1) * B], backend=SimBackend()) for r in range(E)) / E
     loss.backward()
     for r in range(E):
         got = torch.load(tmp_path / f"r{r}.pt")

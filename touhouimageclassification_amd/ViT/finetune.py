@@ -148,9 +148,10 @@ def _nan_guard(loss: float, running: float, i: int, what: str, epoch: int, logge
 
 def train_model(model: torch.nn.Module, dataset, optimizer, scheduler, criterion, batch_size: int, num_epochs: int,
                 max_tolerant_epoch: int, save_path: str, logger: logging.Logger, skip_optimizer_load: bool = False,
-                scheduler_per_epoch: bool = True, num_workers: int = 8, val_fraction_denominator: int = 10) -> List[float]:
+                scheduler_per_epoch: bool = True, num_workers: int = 8, val_fraction_denominator: int = 10, scaler=None) -> List[float]:
     """Epoch loop with resume-from-latest, 90/10 split (seed 0), per-epoch tuple checkpoints and the early-exit rule.
-    Returns the validation-loss timeline."""
+    Returns the validation-loss timeline.  ``scaler``: the reference builds a ``GradScaler`` here for its fp16 autocast
+    (finetune.py:163); bf16 needs none, an enabled one is honoured by ``train_step``."""
     start_epoch = _find_resume_epoch(save_path, num_epochs)
     if start_epoch:
         logger.info(f"Resuming from epoch {start_epoch}")
@@ -173,7 +174,7 @@ def train_model(model: torch.nn.Module, dataset, optimizer, scheduler, criterion
             logger.info(f"LR for epoch {epoch + 1}: {scheduler.get_last_lr()[0]:.6e}")
         running = 0.0
         for i, batch in enumerate(train_loader):
-            loss = train_step(model, batch, optimizer, criterion, None, None if scheduler_per_epoch else scheduler)
+            loss = train_step(model, batch, optimizer, criterion, scaler, None if scheduler_per_epoch else scheduler)
             running += _nan_guard(loss, running, i, "training", epoch, logger)
         return running / len(train_loader) if len(train_loader) else 0.0
 
@@ -210,3 +211,46 @@ def train_model(model: torch.nn.Module, dataset, optimizer, scheduler, criterion
         if scheduler and scheduler_per_epoch:
             scheduler.step()
     return timeline
+
+
+def main(data_dir: Optional[str] = None, num_epochs: int = 40, batch_size: int = 30, lr: float = 1e-5, weight_decay: float = 0.01,
+         use_pretrained: bool = True, scheduler_type: str = 'linear', warmup_steps: int = 500,
+         model_name: str = "google/vit-large-patch16-224-in21k", device: Optional[str] = None, dataset=None, num_workers: int = 8):
+    """the reference's ``__main__`` block (finetune.py:270-342) with its hyper-parameters as defaults: AdamW + per-step linear
+    warm-up schedule, early stopping disabled (tolerance = number of epochs)"""
+    from ..optim import FusedAdamW
+    from ..utils.parameter import CHECKPOINT_DIR, LOG_DIR, UNFILTERED_DATA_DIR, VIT_IMAGE_SIZE
+    from .model import ViT
+    os.makedirs(CHECKPOINT_DIR, exist_ok=True)
+    save_path = os.path.join(CHECKPOINT_DIR, 'ViT_model_finetune_{epoch}.pth')
+    logger = get_logger('ViT_finetune', LOG_DIR)
+    logger.info("Starting ViT training script.")
+    logger.info(f"Parameters: BATCH_SIZE={batch_size}, IMAGE_SIZE={VIT_IMAGE_SIZE}, NUM_EPOCHS={num_epochs}, LR={lr}, PRETRAINED={use_pretrained}")
+    if dataset is None:
+        from ..utils.preprocess import get_dataset
+        data_dir = data_dir or UNFILTERED_DATA_DIR
+        logger.info(f"Loading dataset from {data_dir}...")
+        dataset = get_dataset(data_dir=data_dir, image_size=VIT_IMAGE_SIZE)
+    num_classes = len(dataset.classes)
+    logger.info(f"Dataset loaded. Number of classes: {num_classes}")
+    model = ViT(num_classes=num_classes, pretrained=use_pretrained, model_name=model_name).to(device or "cuda")
+    optimizer = FusedAdamW(model, lr=lr, weight_decay=weight_decay)   # AdamW(model.parameters(), ...) semantics, one HIP kernel
+    criterion = torch.nn.CrossEntropyLoss()
+    num_training_steps = (len(dataset) - len(dataset) // 10) // batch_size * num_epochs
+    scheduler, scheduler_per_epoch = None, True
+    if scheduler_type == 'linear':
+        scheduler = get_linear_schedule_with_warmup(optimizer, num_warmup_steps=warmup_steps, num_training_steps=num_training_steps)
+        scheduler_per_epoch = False
+        logger.info(f"Using linear scheduler with {warmup_steps} warmup steps and {num_training_steps} total steps.")
+    else:
+        logger.info("Not using a learning rate scheduler.")
+    logger.info("Starting model training...")
+    timeline = train_model(model, dataset, optimizer, scheduler, criterion, num_epochs=num_epochs, batch_size=batch_size,
+                           max_tolerant_epoch=num_epochs, save_path=save_path, logger=logger, skip_optimizer_load=False,
+                           scheduler_per_epoch=scheduler_per_epoch, num_workers=num_workers)
+    logger.info("Training finished.")
+    return model, timeline
+
+
+if __name__ == '__main__':
+    main()

@@ -34,13 +34,9 @@ from ..dist import BucketedGradSync
 from ..optim import FusedAdamW
 from .model import TicViTForImageClassification, ViT
 
-# TIC/utils/parameter.py:1-10
-NUM_CLASSES = 120
-VIT_IMAGE_SIZE = (224, 224)
-DATA_DIR = "data/train"
-FILTERED_DATA_DIR = "data/filtered"
-TEST_DIR = "data/test"
-CHECKPOINT_DIR = "checkpoint"
+from ..utils.parameter import (CHECKPOINT_DIR, DATA_DIR, FILTERED_DATA_DIR, NUM_CLASSES, TEST_DIR,  # noqa: F401
+                               UNFILTERED_DATA_DIR, VIT_IMAGE_SIZE)
+
 STAGING_SIZE = 256   # dataset thumbnails are 256x256 (report section 3.1); raw uint8 batches are staged at this size
 
 
@@ -364,7 +360,5 @@ def train_main(PRETRAINED: bool, MODEL_NAME: str, LR: float, WEIGHT_DECAY: float
 
 
 if __name__ == '__main__':
-    # Filtered dataset + full augmentation: the reference's main preset (ntrain.py:250-267)
-    train_main(PRETRAINED=True, MODEL_NAME='google/vit-large-patch16-224', LR=1e-5, WEIGHT_DECAY=0.01, FULL_FINETUNE=True,
-               BATCH_SIZE=8, NUM_WORKERS=4, TRAIN_SPLIT=0.8, TRAIN_ID="nViT", DATA_DIR=FILTERED_DATA_DIR, MAX_EPOCHS=20,
-               ENABLE_MIX_UP=True, ENABLE_AUGMENTATION=True)
+    from .presets import run_preset
+    run_preset("nViT")   # filtered dataset + full augmentation: the reference's main preset (ntrain.py:250-267)

@@ -83,6 +83,11 @@ SIGNATURES = {
     "tic_avgpool_fwd": ([P, P, I, I, I, P], I),
     "tic_avgpool_bwd": ([P, P, I, I, I, P], I),
     "tic_add_bf16": ([P, P, L, P], I),
+    "tic_moe_gate": ([P, P, F, P, P, P, I, I, I, P], I),
+    "tic_moe_gate_bwd": ([P, P, P, I, I, P], I),
+    "tic_moe_combine": ([P, P, P, I, I, I, P], I),
+    "tic_moe_combine_bwd": ([P, P, P, P, P, I, I, I, P], I),
+    "tic_moe_loss": ([P, P, P, P, P, P, I, I, I, F, F, F, P], I),
     "tic_vit_layout": ([C.POINTER(TicVitDims), C.POINTER(TicVitLayout)], I),
     "tic_vit_refresh_weights": ([C.POINTER(TicVitState), I, P], I),
     "tic_vit_forward": ([C.POINTER(TicVitState), P, P, P], I),

@@ -15,6 +15,7 @@
 #include "gemm.h"
 #include "gemm256.h"
 #include "gemm_tn256.h"
+#include "moe.h"
 #include "norm.h"
 
 static thread_local char g_tic_err[512] = "";
@@ -513,6 +514,40 @@ extern "C" int tic_softmax_xent(const float* logits, const int64_t* labels, cons
     TIC_REQUIRE((labels != nullptr) != (soft != nullptr), "softmax_xent: exactly one of labels / soft must be given");
     TIC_LAUNCH(xent_kernel, (B + 3) / 4, 256, 0, stream, logits, (const long long*)labels, soft, loss_sum, dlogits, B, C, gscale);
     return tic_after_launch("softmax_xent");
+}
+
+// ---- mixture of experts: gate / combine / loss (BASELINE config 5) ---------------------------------------
+extern "C" int tic_moe_gate(const float* logits, const float* noise, float noise_scale, float* gate_w, int64_t* topk_idx, float* topk_w,
+                            int B, int E, int K, tic_stream_t stream) {
+    TIC_REQUIRE(logits && gate_w && topk_idx && topk_w, "moe_gate: null pointer");
+    TIC_REQUIRE(B >= 1 && E >= 1 && E <= 64 && K >= 1 && K <= TIC_MOE_MAX_K && K <= E, "moe_gate: need 1 <= K <= min(E, %d), E <= 64 (B=%d E=%d K=%d)", TIC_MOE_MAX_K, B, E, K);
+    TIC_LAUNCH(moe_gate_kernel, (B + 3) / 4, 256, 0, stream, logits, noise, noise_scale, gate_w, (long long*)topk_idx, topk_w, B, E, K);
+    return tic_after_launch("moe_gate");
+}
+extern "C" int tic_moe_gate_bwd(const float* gate_w, const float* d_gate_w, float* dlogits, int B, int E, tic_stream_t stream) {
+    TIC_REQUIRE(gate_w && d_gate_w && dlogits && B >= 1 && E >= 1 && E <= 64, "moe_gate_bwd: bad argument");
+    TIC_LAUNCH(moe_gate_bwd_kernel, (B + 3) / 4, 256, 0, stream, gate_w, d_gate_w, dlogits, B, E);
+    return tic_after_launch("moe_gate_bwd");
+}
+extern "C" int tic_moe_combine(const float* expert_out, const float* gate_w, float* out, int B, int E, int C, tic_stream_t stream) {
+    TIC_REQUIRE(expert_out && gate_w && out && B >= 1 && E >= 1 && C >= 1, "moe_combine: bad argument");
+    TIC_LAUNCH(moe_combine_kernel, (int)(((long)B * C + 255) / 256), 256, 0, stream, expert_out, gate_w, out, B, E, C);
+    return tic_after_launch("moe_combine");
+}
+extern "C" int tic_moe_combine_bwd(const float* expert_out, const float* gate_w, const float* dout, float* d_expert_out, float* d_gate_w,
+                                   int B, int E, int C, tic_stream_t stream) {
+    TIC_REQUIRE(expert_out && gate_w && dout && d_expert_out && d_gate_w && B >= 1 && E >= 1 && C >= 1, "moe_combine_bwd: bad argument");
+    TIC_LAUNCH(moe_combine_bwd_kernel, (int)(((long)B * E + 3) / 4), 256, 0, stream, expert_out, gate_w, dout, d_expert_out, d_gate_w, B, E, C);
+    return tic_after_launch("moe_combine_bwd");
+}
+extern "C" int tic_moe_loss(const float* logits, const float* targets, const float* gate_w, float* loss3, float* dlogits, float* d_gate_w,
+                            int B, int C, int E, float a_ce, float b_rce, float a_balance, tic_stream_t stream) {
+    TIC_REQUIRE(logits && targets && loss3 && B >= 1 && C >= 1, "moe_loss: bad argument");
+    TIC_REQUIRE(!gate_w || (E >= 1 && E <= 64), "moe_loss: E must be 1..64");
+    TIC_RT_MEMSET(loss3, 0, 3 * sizeof(float), stream);
+    TIC_LAUNCH(moe_loss_rows_kernel, (B + 3) / 4, 256, 0, stream, logits, targets, loss3, dlogits, B, C, a_ce, b_rce);
+    if (gate_w) TIC_LAUNCH(moe_balance_kernel, 1, 64, 0, stream, gate_w, loss3, d_gate_w, B, E, a_balance);
+    return tic_after_launch("moe_loss");
 }
 
 // ---- augmentation ----------------------------------------------------------------------------------

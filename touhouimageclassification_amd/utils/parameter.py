@@ -1,23 +1,25 @@
-"""Project-wide defaults shared by the harnesses (values of TIC/utils/parameter.py:1-16; names kept for drop-in imports)."""
+"""Project-wide defaults shared by the harnesses: the VALUES of TIC/utils/parameter.py:1-16 under the same names, so that
+``from ...utils.parameter import *`` in a harness written for the reference resolves to the same directories and sizes."""
 from typing import Tuple
 
-NUM_CLASSES = 120                      # dataset categories
+NUM_CLASSES = 120                      # dataset categories (parameter.py:1)
 
-# image geometry: dataset thumbnails are 256 x 256, every ViT variant is fed 224 x 224
+# image geometry: dataset thumbnails are 256 x 256 (ResNet input), every ViT variant is fed 224 x 224 (parameter.py:2-3)
 IMAGE_SIZE: Tuple[int, int] = (256, 256)
 VIT_IMAGE_SIZE: Tuple[int, int] = (224, 224)
 
-# directory layout relative to the working directory
-_DATA_ROOT = "data"
-DATA_DIR = f"{_DATA_ROOT}/train"
-UNFILTERED_DATA_DIR = DATA_DIR
-FILTERED_DATA_DIR = f"{_DATA_ROOT}/filtered"
-TEST_DIR = f"{_DATA_ROOT}/test"
+# directory layout relative to the working directory (parameter.py:4-10)
+DATA_DIR = "data"
+UNFILTERED_DATA_DIR = f"{DATA_DIR}/unfiltered"
+FILTERED_DATA_DIR = f"{DATA_DIR}/data_filtered_vit_base"
+TEST_DIR = f"{DATA_DIR}/testset"
 CHECKPOINT_DIR = "checkpoint"
 LOG_DIR = "log"
+CACHE_DIR = "cache"
 
 
-def get_image_size(model_name: str) -> Tuple[int, int]:
-    """input resolution for a model name: ViT variants 224 x 224, everything else the thumbnail size (parameter.py:12-16)"""
-    is_vit = "vit" in model_name.lower()
-    return VIT_IMAGE_SIZE if is_vit else IMAGE_SIZE
+def get_image_size(model_type: str) -> Tuple[int, int]:
+    """input resolution by model type: ViT variants and the ViT-expert MoE 224 x 224, everything else the thumbnail size
+    (parameter.py:12-16)"""
+    kind = model_type.lower()
+    return VIT_IMAGE_SIZE if ("vit" in kind or "resmoe" in kind) else IMAGE_SIZE
