@@ -260,7 +260,7 @@ def test_serve_and_full_judge_match_oracle(tmp_path):
     torch.manual_seed(0)
     model = ViT(len(classes), pretrained=False, model_name="tiny")
     with torch.no_grad():
-        model.classifier.weight.mul_(40.0)   # widen the logit margins of the random-init head so top-1 is decided by more than bf16 noise
+        model.classifier.weight.mul_(8.0)   # widen the logit margins of the random-init head
     torch.save((model.state_dict(), {}), tmp_path / "ck.pth")   # finetune.py:249-258 tuple format
     m2 = ViT(len(classes), pretrained=False, model_name="tiny")
     m2.load_state_dict(torch.load(tmp_path / "ck.pth", weights_only=False)[0])
@@ -273,19 +273,24 @@ def test_serve_and_full_judge_match_oracle(tmp_path):
     spec = vo.ViTSpec(**vo.VIT_TINY, num_labels=len(classes))
     params = _cpu_params(m2)
     idx_to_class = {v: k for k, v in c2i.items()}
-    n_ok = 0
+    n_ok = n_decided = 0
     for ln in lines[1:]:
         fname, pred, conf, actual, correct, path = ln.split(",")
         raw = sv._load_u8(path, 64).unsqueeze(0).to(DEV)
         with torch.no_grad():
-            ref = vo.forward(params, tf(raw).cpu(), spec)[0]
-        prob = torch.softmax(ref, -1)
+            xin = tf(raw)
+            hip = m2(xin).logits[0].cpu()
+            ref = vo.forward(params, xin.cpu(), spec)[0]
+        torch.testing.assert_close(hip, ref, atol=2e-2, rtol=2e-2)                  # the forward itself, at the usual tolerance
+        assert pred == idx_to_class[int(hip.argmax())]                              # the CSV row is this forward's argmax ...
+        assert abs(float(conf) - float(torch.softmax(ref, -1)[c2i[pred]])) < 2e-2   # ... and the oracle's confidence for it
         srt = ref.sort(descending=True).values
-        if srt[0] - srt[1] > 4e-2:    # decided by more than the logit tolerance
+        if srt[0] - srt[1] > 2 * float((hip - ref).abs().max()) + 1e-3:             # top-1 decided by more than the observed difference
             assert pred == idx_to_class[int(ref.argmax())], ln
-        assert abs(float(conf) - float(prob[c2i[pred]])) < 2e-2
+            n_decided += 1
         assert actual == os.path.basename(os.path.dirname(path)) and correct == str(pred == actual)
         n_ok += pred == actual
+    assert n_decided >= 9, n_decided
     assert abs(acc - n_ok / 18) < 1e-9
     # single image -> (class, confidence) through `serve`
     p0 = str(data / "reimu" / "0.png")

@@ -111,7 +111,9 @@ def test_headline_shape_properties():
     l1 = m(x).logits
     l2 = m(x).logits
     assert torch.isfinite(l1).all() and torch.equal(l1, l2)
-    loss = torch.nn.functional.cross_entropy(l1, y)
+    with pytest.raises(RuntimeError, match="activations saved by this forward are gone"):
+        torch.nn.functional.cross_entropy(l1, y).backward()   # l1's workspace was re-used by the second forward: detected, not differentiated
+    loss = torch.nn.functional.cross_entropy(l2, y)
     assert abs(loss.item() - np.log(120)) < 0.5
     loss.backward()
     g1 = m._engine.grads.clone()

@@ -85,12 +85,15 @@ def test_gemm_tn_group(env, M, shapes):
     from touhouimageclassification_amd._lib import call
     call("tic_set_option", b"gemm_tile", 256)
     try:
-        for sk in (0, 1, 7, 100):   # full-M tiles; 256 / 7 / 100 stream-K shares (partial tiles, shares crossing problems)
-            call("tic_set_option", b"tn_streamk", sk)
-            kc.check_gemm_tn_group(env, M, shapes)
+        for mfma in (16, 32):           # MFMA shape of the stream-K launch: 16x16x32 (default) and 32x32x16
+            call("tic_set_option", b"tn_mfma", mfma)
+            for sk in (0, 1, 7, 100):   # full-M tiles; 256 / 7 / 100 stream-K shares (partial tiles, shares crossing problems)
+                call("tic_set_option", b"tn_streamk", sk)
+                kc.check_gemm_tn_group(env, M, shapes)
     finally:
         call("tic_set_option", b"gemm_tile", 0)
         call("tic_set_option", b"tn_streamk", 1)
+        call("tic_set_option", b"tn_mfma", 16)
 
 
 @pytest.mark.parametrize("S,H,W", [(32, 40, 48), (224, 256, 256)])

@@ -98,12 +98,16 @@ def test_fused_bias_gradients(env):
     kc.check_fused_bias_gradients(env)
 
 
-def test_gemm_tn_group_phase_aligned_split(env):
-    """16 shares over 8 tiles: per 'XCD' one main workgroup (steps [0, S/2)) and one tail workgroup (steps [S/2, S))"""
+@pytest.mark.parametrize("mfma", [16, 32])
+def test_gemm_tn_group_phase_aligned_split(env, mfma):
+    """16 shares over 8 tiles: per 'XCD' one main workgroup (steps [0, S/2)) and one tail workgroup (steps [S/2, S)); both MFMA
+    shapes of the stream-K launch (16x16x32: the default; 32x32x16: kept for A/B measurements)"""
     call("tic_set_option", b"gemm_tile", 256)
     call("tic_set_option", b"tn_streamk", 16)
+    call("tic_set_option", b"tn_mfma", mfma)
     try:
         kc.check_gemm_tn_group(env, 333, [(512, 512), (256, 1024)])
     finally:
         call("tic_set_option", b"gemm_tile", 0)
         call("tic_set_option", b"tn_streamk", 1)
+        call("tic_set_option", b"tn_mfma", 16)

@@ -283,6 +283,236 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
             }
 }
 
+// The same tile segment on v_mfma_f32_16x16x32_bf16 (the NT kernel's instruction).  Cycles per FLOP equal those of the 32x32x16
+// form, but the chip holds a higher clock on this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.15 x the
+// FLOP/s in LDS-fed loops on random data), and the kernel is MFMA-clock-bound once its reads are hidden.
+// What changes against the 32x32 form above:
+//   fragments   a lane holds 8 consecutive m (reduction) values of ONE column of a 16-column block: lane (g = l>>4, q = (l>>2)&3,
+//               p = l&3) addresses row 32 ks + 8 g + q (+4 for the second read), columns 4p..4p+3; the transposing read hands
+//               lane i of each 16-lane group column i of those 4 rows.  A: 4 blocks (mt) of 16 n, B: 2 blocks (nt) of 16 k.
+//   swizzle     one read instruction covers rows {8 g + q : g in a pair, q = 0..3} = 8 rows x 32 B; the 256-B bank row has 8
+//               such slots, so the 16-B chunk index is XORed with (q << 2) ^ ((g & 1) << 1) on both sides (DMA source and read).
+//   D layout    col = l & 15 -> k (16 contiguous fp32 = 64 B per row and instruction), row = 4 (l >> 4) + reg -> n.
+template <bool ATOMIC>
+TIC_DEV void tn256_tile_segment16(const bf16_t* Ap, const bf16_t* Bp, float* Cp, int N, int K, int M, int n0, int k0, int step0, int step1) {
+    const int tid = TIC_TID, l = tid & 63, w = wave_id();
+    const int wr = w >> 2, wc = w & 3;
+    const int row_end = (step1 * 64 < M) ? step1 * 64 : M;
+    const tic_rsrc_t ra = make_rsrc(Ap, (uint32_t)((size_t)row_end * N * 2));
+    const tic_rsrc_t rb = make_rsrc(Bp, (uint32_t)((size_t)row_end * K * 2));
+
+    // ---- LDS-DMA: half-tile = [64 m][128 cols] = 16 pieces of 4 rows; this wave moves pieces 2w, 2w+1 (rows 8w .. 8w+7:
+    // (row >> 3) & 1 == w & 1 for both pieces)
+    const uint32_t rr = (uint32_t)l >> 4, ch_log = ((uint32_t)l & 15u) ^ (rr << 2) ^ (((uint32_t)w & 1u) << 1);
+    uint32_t voa[2][2], vob[2][2];   // [half][piece], running
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t row = (uint32_t)step0 * 64u + (uint32_t)(2 * w + j) * 4 + rr;
+            voa[h][j] = (uint32_t)(((size_t)row * N + n0 + h * 128 + ch_log * 8) * 2);
+            vob[h][j] = (uint32_t)(((size_t)row * K + k0 + h * 128 + ch_log * 8) * 2);
+        }
+    const uint32_t stepA = (uint32_t)N * 128u, stepB = (uint32_t)K * 128u;   // 64 rows in bytes
+    auto issue = [&](int buf, int which) {   // which: 0 = A0, 1 = B0, 2 = B1, 3 = A1
+        const bool isA = (which == 0 || which == 3);
+        const int h = (which >= 2) ? 1 : 0;
+        const uint32_t base = (uint32_t)buf * G256_BUF_BYTES + (isA ? 0u : 32768u) + (uint32_t)h * 16384u + (uint32_t)(2 * w) * 1024u;
+        if (isA) {
+            glds16(ra, base, voa[h][0], 0);
+            glds16(ra, base + 1024u, voa[h][1], 0);
+            voa[h][0] += stepA;
+            voa[h][1] += stepA;
+        } else {
+            glds16(rb, base, vob[h][0], 0);
+            glds16(rb, base + 1024u, vob[h][1], 0);
+            vob[h][0] += stepB;
+            vob[h][1] += stepB;
+        }
+    };
+
+    const uint32_t g4 = (uint32_t)l >> 4, q4 = ((uint32_t)l >> 2) & 3u, p4 = (uint32_t)l & 3u;
+    auto lane_addr = [&](uint32_t col0) -> uint32_t {   // col0: multiple of 16
+        const uint32_t col = col0 + 4 * p4;
+        const uint32_t row = 8 * g4 + q4;                 // (row & 3) == q4 and ((row >> 3) & 1) == (g4 & 1) for both reads and every ks
+        return lds_base() + row * 256u + (((col >> 3) ^ (q4 << 2) ^ ((g4 & 1u) << 1)) * 16u) + (col & 4u) * 2u;
+    };
+    uint32_t a_lane[4], b_lane[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a_lane[mt] = lane_addr((uint32_t)wr * 64 + (uint32_t)mt * 16);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) b_lane[nt] = lane_addr((uint32_t)wc * 32 + (uint32_t)nt * 16);
+    auto tr_frag = [&](uint32_t addr, uint32_t imm) -> bf16x8 {
+        const bf16x4 lo = lds_tr64_hidden(addr, imm);
+        const bf16x4 hi = lds_tr64_hidden(addr, imm + 1024u);
+        return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+
+    f32x4 acc[2][2][4][2];   // [i][j][mt][nt]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa0[4][2], fa1[4][2], fbx[2][2], fby[2][2];   // [mt][ks], [nt][ks]
+    // two of the four A blocks of one ks (4 reads)
+    auto rd_a2 = [&](uint32_t bufb, int i, bf16x8 (&fa)[4][2], uint32_t ks, int m0) {
+#pragma unroll
+        for (int mt = m0; mt < m0 + 2; ++mt) fa[mt][ks] = tr_frag(a_lane[mt] + bufb, (uint32_t)i * 16384u + ks * 8192u);
+    };
+    // one B block, both ks (4 reads)
+    auto rd_b1 = [&](uint32_t bufb, int j, bf16x8 (&fb)[2][2], int nt) {
+#pragma unroll
+        for (uint32_t ks = 0; ks < 2; ++ks) fb[nt][ks] = tr_frag(b_lane[nt] + bufb, 32768u + (uint32_t)j * 16384u + ks * 8192u);
+    };
+    // 4 MFMAs: A blocks m0, m0+1 x both B blocks, one ks
+    auto mma4 = [&](int i, int j, const bf16x8 (&fa)[4][2], const bf16x8 (&fb)[2][2], int ks, int m0) {
+#pragma unroll
+        for (int mt = m0; mt < m0 + 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[i][j][mt][nt] = mfma16(fa[mt][ks], fb[nt][ks], acc[i][j][mt][nt]);
+    };
+    // one 64-row step; on entry B0(t) is in fbp and ks 0 of A0(t) in fa0[.][0]; on exit the same for t+1 with fbq.  Same load /
+    // wait / barrier skeleton as the 32x32 form; inside an MFMA segment groups of 4 MFMAs alternate with groups of 4 hidden reads.
+    auto step = [&](int st, bf16x8 (&fbp)[2][2], bf16x8 (&fbq)[2][2]) {
+        const int cur = st & 1;
+        const uint32_t bufb = (uint32_t)cur * G256_BUF_BYTES, bufn = (uint32_t)(cur ^ 1) * G256_BUF_BYTES;
+        // ---- phase 0: Q00 = A0 x B0 ; reads A0(t) ks 1 and B1(t)
+        issue(cur ^ 1, 3);   // A1(t+1)
+        wait_vmcnt<8>();
+        g256_barrier();
+        prio_hi();
+        rd_a2(bufb, 0, fa0, 1, 0);
+        sched_fence();
+        mma4(0, 0, fa0, fbp, 0, 0);
+        sched_fence();
+        rd_a2(bufb, 0, fa0, 1, 2);
+        sched_fence();
+        mma4(0, 0, fa0, fbp, 0, 2);
+        sched_fence();
+        rd_b1(bufb, 1, fbq, 0);
+        lds_wait<4>(fa0[0][1], fa0[1][1], fa0[2][1], fa0[3][1]);   // the 4 B1 reads may still be out
+        sched_fence();
+        mma4(0, 0, fa0, fbp, 1, 0);
+        sched_fence();
+        rd_b1(bufb, 1, fbq, 1);
+        sched_fence();
+        mma4(0, 0, fa0, fbp, 1, 2);
+        sched_fence();
+        lds_wait<0>(fbq[0][0], fbq[0][1], fbq[1][0], fbq[1][1]);
+        prio_lo();
+        g256_barrier();
+        // ---- phase 1: Q01 = A0 x B1 ; reads A1(t) ks 0
+        issue(cur, 1);       // B0(t+2)
+        wait_vmcnt<8>();
+        g256_barrier();
+        prio_hi();
+        mma4(0, 1, fa0, fbq, 0, 0);
+        sched_fence();
+        rd_a2(bufb, 1, fa1, 0, 0);
+        sched_fence();
+        mma4(0, 1, fa0, fbq, 0, 2);
+        sched_fence();
+        rd_a2(bufb, 1, fa1, 0, 2);
+        sched_fence();
+        mma4(0, 1, fa0, fbq, 1, 0);
+        mma4(0, 1, fa0, fbq, 1, 2);
+        sched_fence();
+        lds_wait<0>(fa1[0][0], fa1[1][0], fa1[2][0], fa1[3][0]);
+        prio_lo();
+        g256_barrier();
+        // ---- phase 2: Q11 = A1 x B1 ; reads A1(t) ks 1
+        issue(cur, 0);       // A0(t+2)
+        wait_vmcnt<8>();
+        g256_barrier();
+        prio_hi();
+        rd_a2(bufb, 1, fa1, 1, 0);
+        sched_fence();
+        mma4(1, 1, fa1, fbq, 0, 0);
+        sched_fence();
+        rd_a2(bufb, 1, fa1, 1, 2);
+        sched_fence();
+        mma4(1, 1, fa1, fbq, 0, 2);
+        sched_fence();
+        lds_wait<0>(fa1[0][1], fa1[1][1], fa1[2][1], fa1[3][1]);
+        sched_fence();
+        mma4(1, 1, fa1, fbq, 1, 0);
+        mma4(1, 1, fa1, fbq, 1, 2);
+        prio_lo();
+        g256_barrier();
+        // ---- phase 3: Q10 = A1 x B0 ; reads A0(t+1) ks 0 and B0(t+1)
+        issue(cur, 2);       // B1(t+2)
+        wait_vmcnt<8>();
+        g256_barrier();
+        prio_hi();
+        mma4(1, 0, fa1, fbp, 0, 0);
+        sched_fence();
+        rd_a2(bufn, 0, fa0, 0, 0);
+        sched_fence();
+        mma4(1, 0, fa1, fbp, 0, 2);
+        sched_fence();
+        rd_a2(bufn, 0, fa0, 0, 2);
+        sched_fence();
+        mma4(1, 0, fa1, fbp, 1, 0);
+        sched_fence();
+        rd_b1(bufn, 0, fbq, 0);
+        sched_fence();
+        mma4(1, 0, fa1, fbp, 1, 2);
+        sched_fence();
+        rd_b1(bufn, 0, fbq, 1);
+        lds_wait<0>(fa0[0][0], fa0[1][0], fa0[2][0], fa0[3][0], fbq[0][0], fbq[0][1], fbq[1][0], fbq[1][1]);
+        prio_lo();
+        g256_barrier();
+    };
+
+    issue(0, 1);
+    issue(0, 0);
+    issue(0, 2);
+    issue(0, 3);
+    issue(1, 1);
+    issue(1, 0);
+    issue(1, 2);
+    wait_vmcnt<8>();
+    g256_barrier();
+    rd_a2(0u, 0, fa0, 0, 0);
+    rd_a2(0u, 0, fa0, 0, 2);
+    rd_b1(0u, 0, fbx, 0);
+    rd_b1(0u, 0, fbx, 1);
+    lds_wait<0>(fa0[0][0], fa0[1][0], fa0[2][0], fa0[3][0], fbx[0][0], fbx[0][1], fbx[1][0], fbx[1][1]);
+    if (wr == 1) g256_barrier();
+
+    const int nsteps = step1 - step0;
+#pragma nounroll
+    for (int st = 0; st < nsteps; st += 2) {
+        step(st, fbx, fby);
+        step(st + 1, fby, fbx);
+    }
+    wait_vmcnt0();
+    if (wr == 0) g256_barrier();
+
+    // C += acc : D column = l & 15 -> k (contiguous), row = 4 (l >> 4) + reg -> n
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int kk = k0 + j * 128 + wc * 32 + nt * 16 + (l & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + i * 128 + wr * 64 + mt * 16 + 4 * (l >> 4) + r;
+                        float* dst = Cp + (size_t)n * K + kk;
+                        if (ATOMIC) atomic_addf(dst, acc[i][j][mt][nt][r]);
+                        else *dst = *dst + acc[i][j][mt][nt][r];
+                    }
+                }
+}
+
 template <int DBG = 0>
 __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp) {
     // XCD-contiguous tile order, then problem lookup (wave-uniform)
@@ -311,7 +541,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
 // s_main == 0 -- FLAT split: the flattened (tile, step) space cut into gridDim.x equal contiguous shares.
 // body shared by the two kernel names below (a macro, not a function: passing the by-value kernel argument struct on to a
 // function makes hipcc copy it to scratch -- +136 B/lane, +21 VGPRs, 8 % slower)
-#define TN256_STREAMK_BODY \
+#define TN256_STREAMK_BODY(SEG) \
     const bf16_t *Ap, *Bp; \
     float* Cp; \
     int N, K, n0, k0; \
@@ -319,11 +549,11 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
         const int xcd = TIC_BID_X & 7, idx = TIC_BID_X >> 3;   /* blocks b, b+8, ... share an XCD (speed only, never correctness) */ \
         if (idx < tpx) { \
             tn_tile_lookup(gp, xcd * tpx + idx, Ap, Bp, Cp, N, K, n0, k0); \
-            tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, s_main); \
+            SEG<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, s_main); \
         } else { \
             for (int j = 0; j < tail_each; ++j) { \
                 tn_tile_lookup(gp, xcd * tpx + (idx - tpx) * tail_each + j, Ap, Bp, Cp, N, K, n0, k0); \
-                tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s_main, nsteps); \
+                SEG<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s_main, nsteps); \
             } \
         } \
         return; \
@@ -336,16 +566,20 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
         int s1 = s0 + (u1 - u); \
         if (s1 > nsteps) s1 = nsteps; \
         tn_tile_lookup(gp, tile, Ap, Bp, Cp, N, K, n0, k0); \
-        tn256_tile_segment<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s0, s1); \
+        SEG<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s0, s1); \
         u += s1 - s0; \
     }
 
 // the grouped launch of one transformer block (the step's dominant kernel: bench.py times exactly these launches) ...
 __global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
-    TN256_STREAMK_BODY
+    TN256_STREAMK_BODY(tn256_tile_segment16)
+}
+// the 32x32x16-MFMA form of the same launch (tic_set_option("tn_mfma", 32): A/B measurements)
+__global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_mfma32_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
+    TN256_STREAMK_BODY(tn256_tile_segment)
 }
 // ... and the same code under its own name for single weight-gradient problems routed here by tic_gemm_tn_bf16 (patch embedding,
 // ResNet 1x1 convolutions), so that per-kernel profiler averages of the block launch stay clean
 __global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_single_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
-    TN256_STREAMK_BODY
+    TN256_STREAMK_BODY(tn256_tile_segment16)
 }

@@ -55,6 +55,7 @@ static int g_opt_tn_main_bias = 0;   // extra M steps given to the 'main' workgr
 static int g_opt_gemm_dbg = 0;
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
+static int g_opt_tn_mfma = 16;    // grouped dW stream-K launch on v_mfma_f32_16x16x32_bf16 (default) or 32x32x16 (A/B)
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 extern "C" int tic_set_option(const char* name, int value) {
     if (name && !strcmp(name, "ln_blocks") && value >= 64 && value <= 65536) {
@@ -87,6 +88,10 @@ extern "C" int tic_set_option(const char* name, int value) {
     }
     if (name && !strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) {
         g_opt_gemm_tile = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "tn_mfma") && (value == 16 || value == 32)) {
+        g_opt_tn_mfma = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "tn_phase") && (value == 0 || value == 1)) {
@@ -290,9 +295,14 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
                 TIC_LAUNCH(gemm_tn256_streamk_single_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
                 return tic_after_launch("gemm_tn(stream-K)");
             }
-            TIC_RT_MAX_LDS(gemm_tn256_streamk_kernel, G256_LDS_BYTES);
             TIC_RT_TIMER_MARK(0, stream);
-            TIC_LAUNCH(gemm_tn256_streamk_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
+            if (g_opt_tn_mfma == 32) {
+                TIC_RT_MAX_LDS(gemm_tn256_streamk_mfma32_kernel, G256_LDS_BYTES);
+                TIC_LAUNCH(gemm_tn256_streamk_mfma32_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
+            } else {
+                TIC_RT_MAX_LDS(gemm_tn256_streamk_kernel, G256_LDS_BYTES);
+                TIC_LAUNCH(gemm_tn256_streamk_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
+            }
             TIC_RT_TIMER_MARK(1, stream);
             return tic_after_launch("gemm_tn_group(stream-K)");
         }
