@@ -8,7 +8,9 @@
  *
  * Conventions
  *   - plain pointers and sizes only; the CALLER owns every buffer (the library never allocates or
- *     frees device memory and keeps no mutable global state besides the last-error string);
+ *     frees device memory).  Process-wide mutable state: the thread-local last-error string, the
+ *     tuning knobs of tic_set_option (A/B measurements; set them before, not during, concurrent
+ *     use from several threads) and the event table of tic_kernel_timer_* (one user at a time);
  *   - every call enqueues asynchronously on `stream` (a hipStream_t; pass torch's current stream)
  *     and returns 0, or a negative TIC_E* code with tic_last_error_string() set;
  *   - bf16 tensors are raw 16-bit storage (`void*`), fp32 tensors `float*`, all contiguous
@@ -39,9 +41,9 @@ const char* tic_last_error_string(void);
  *   "stream_nt"  bit mask, default 13       non-temporal cache policy: 1 LayerNorm, 2 AdamW, 4 GEMM epilogue stores, 8 epilogue operand loads
  *   "attn_fwd_waves" 8 | 4                   waves per (image, head) workgroup of the attention forward
  *   "gemm_stagger" -1 (auto) | 0 | n        s_sleep rounds by which every other first-wave workgroup of the 256x256 NT kernel starts late
- *   "gemm_dbg"   0..15                      measurement builds of the 256x256 kernels with parts of the main loop compiled
- *                                           out (bit 0 no LDS-DMA, 1 no fragment reads, 2 no MFMA, 3 deeper queue): GARBAGE
- *                                           results by construction, tools/gemm_dbg.py only */
+ * Builds that produce garbage by construction (parts of the GEMM main loops compiled out, "gemm_dbg") and the in-kernel stage
+ * stamps exist only in the measurement library libtic_hip_dbg.so (-DTIC_MEASURE, `python -m touhouimageclassification_amd.build dbg`;
+ * tools/gemm_dbg.py, tools/tile_timeline.py), never in libtic_hip.so. */
 int tic_set_option(const char* name, int value);
 /* Live timing of the step's dominant kernel (the grouped dW launch of tic_gemm_tn_group_bf16 / tic_vit_backward_layer): while
  * enabled, HIP events are recorded on the launch stream around every such launch (up to 8192); read() waits for them and

@@ -325,6 +325,7 @@ TIC_DEV float shfl_xor(float v, int mask) {
     });
 }
 TIC_DEV int lane_id() { return sim::cur_lane(); }
+TIC_DEV int lane_id_fresh() { return lane_id(); }
 TIC_DEV int wave_id() { return sim::st().cur->tid >> 6; }
 TIC_DEV uint32_t uniform(uint32_t v) { return v; }
 TIC_DEV void atomic_addf(float* p, float v) { *p += v; }

@@ -10,6 +10,9 @@ from touhouimageclassification_amd.optim import FusedAdamW  # noqa: E402
 from touhouimageclassification_amd.step import fused_train_step  # noqa: E402
 
 name, va, vb = sys.argv[1].encode(), int(sys.argv[2]), int(sys.argv[3])
+for kv in filter(None, os.environ.get("TIC_PRESET", "").split(",")):   # other knobs held fixed for the run: TIC_PRESET=a=1,b=2
+    k, v = kv.split("=")
+    call("tic_set_option", k.encode(), int(v))
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 332
 dev = torch.device("cuda")
 m = ViT(120, pretrained=False, model_name="google/vit-large-patch16-224").to(dev)

@@ -4,6 +4,8 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from touhouimageclassification_amd import build  # noqa: E402
+os.environ["TIC_HIP_LIB"] = build.build_hip_dbg()   # the ablation variants live only in the measurement library (-DTIC_MEASURE)
 from touhouimageclassification_amd._lib import call, current_stream  # noqa: E402
 
 dev = torch.device("cuda")

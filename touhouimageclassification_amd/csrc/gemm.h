@@ -42,6 +42,9 @@ struct GemmNtParams {
     int nt;                  // 256x256 staged epilogue: bit 0 non-temporal output stores, bit 1 non-temporal operand loads
     int gm;                  // m-tiles per group of the XCD-local tile walk (tile_coords), 0 = 8
     int stagger;             // experiment (tic_set_option "gemm_stagger"): s_sleep rounds for every other first-wave workgroup
+#ifdef TIC_MEASURE
+    unsigned long long* stamps;   // measurement build only: [grid][8] s_memrealtime stamps of the 256x256 kernel's stages, or nullptr
+#endif
 };
 
 // 16-byte-chunk XOR swizzle for 128-byte LDS rows: conflict-free for the 16x16x32 row-fragment

@@ -43,6 +43,25 @@
 #define G256_LDS_BYTES (2u * G256_BUF_BYTES)
 #define G256_NT_LDS_BYTES (G256_LDS_BYTES + 8192u)   // + [8 waves][256] fp32 column-sum partials of the staged epilogue
 
+// measurement build (-DTIC_MEASURE, libtic_hip_dbg.so): lane 0 of every workgroup stamps the constant 100 MHz clock at the stage
+// boundaries of its tile into p.stamps (tools/tile_timeline.py).  The product build compiles none of it.
+#if defined(TIC_MEASURE) && !defined(TIC_SIM)
+#define G256_STAMP(i)                                                                                            \
+    do {                                                                                                         \
+        if (p.stamps && TIC_TID == 0) p.stamps[(size_t)TIC_BID_X * 8 + (i)] = __builtin_amdgcn_s_memrealtime();  \
+    } while (0)
+#define G256_STAMP_ID()                                                                                          \
+    do {                                                                                                         \
+        if (p.stamps && TIC_TID == 0) {                                                                          \
+            p.stamps[(size_t)TIC_BID_X * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   /* HW_ID */ \
+            p.stamps[(size_t)TIC_BID_X * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  /* XCC_ID */ \
+        }                                                                                                        \
+    } while (0)
+#else
+#define G256_STAMP(i) do { } while (0)
+#define G256_STAMP_ID() do { } while (0)
+#endif
+
 TIC_DEV void g256_barrier() {
 #ifndef TIC_SIM
     asm volatile("" ::: "memory");
@@ -75,29 +94,34 @@ TIC_DEV float bf_hi(uint32_t u) {
 }
 
 // 8 columns per thread: the bf16-output epilogues.  c16 = tid & 31, rows (tid >> 5) + 16 k.
+// The extra operand of the DGELU / MULAUX epilogues (the saved pre-activation / derivative tile, 128 KiB per workgroup) is fetched
+// in ONE go BEFORE the staging pass: once the K loop has ended the 80 fragment registers are free, so all 16 rows of a thread
+// (64 registers) can be in flight while the accumulators are packed and parked in LDS.  Fetched 4 rows deep inside the second pass
+// (the round-1 form) the tile's operand arrived latency-bound: the second pass of fc2^T * gelu' took 9.0 us against 2.2 us for a
+// plain bf16 tile (tools/tile_timeline.py --in-step).
+#define G256_AUX_EARLY 12   // rows fetched before the staging pass (48 registers beside the 128 accumulators); the last 4 follow it
+template <bool NTL, int K0, int K1>
+TIC_DEV void g256_fetch_aux(const GemmNtParams& p, int tid, int m0, int n0, u32x4 (&aux)[16]) {
+    const int c16 = tid & 31, rsub = tid >> 5;
+    const int n = n0 + c16 * 8;
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        const int m = m0 + k * 16 + rsub;
+        aux[k] = (m < p.M) ? ld_u4<NTL>(p.aux + (size_t)m * p.N + n) : u32x4{0u, 0u, 0u, 0u};
+    }
+}
+
 template <int EPI, bool NTS, bool NTL>
-TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
-    constexpr bool HAS_AUX = (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
+TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int tid, int m0, int n0, u32x4 (&aux)[16]) {
     constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
+    if (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX) g256_fetch_aux<NTL, G256_AUX_EARLY, 16>(p, tid, m0, n0, aux);
     constexpr int PF = 4;
-    const int tid = TIC_TID, c16 = tid & 31, rsub = tid >> 5;
+    const int c16 = tid & 31, rsub = tid >> 5;
     const int n = n0 + c16 * 8;
     const uint32_t lds0 = (uint32_t)rsub * 512u + (uint32_t)(((c16 * 2) ^ (rsub << 2)) * 8);
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    u32x4 aux[2][PF];
-    auto fetch = [&](int b) {
-        if (HAS_AUX) {
-#pragma unroll
-            for (int i = 0; i < PF; ++i) {
-                const int m = m0 + (b * PF + i) * 16 + rsub;
-                aux[b & 1][i] = (m < p.M) ? ld_u4<NTL>(p.aux + (size_t)m * p.N + n) : u32x4{0u, 0u, 0u, 0u};
-            }
-        }
-    };
-    fetch(0);
 #pragma unroll
     for (int b = 0; b < 16 / PF; ++b) {
-        if (b + 1 < 16 / PF) fetch(b + 1);
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int k = b * PF + i;
@@ -129,7 +153,7 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
                 st_u4<NTS>(p.out + o, dg);
                 st_u4<NTS>(p.out2 + o, g);
             } else {   // DGELU / MULAUX
-                const u32x4 a = aux[b & 1][i];
+                const u32x4 a = aux[k];
                 u32x4 d;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -165,9 +189,9 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int m0, int n0) {
 
 // 4 columns per thread: the fp32-output epilogues (RESID, PATCH).  c8 = tid & 63, rows (tid >> 6) + 8 k.
 template <int EPI, bool NTS, bool NTL>
-TIC_DEV void g256_finish_f32(const GemmNtParams& p, int m0, int n0) {
+TIC_DEV void g256_finish_f32(const GemmNtParams& p, int tid, int m0, int n0) {
     constexpr int PF = 4;
-    const int tid = TIC_TID, c8 = tid & 63, rsub = tid >> 6;
+    const int c8 = tid & 63, rsub = tid >> 6;
     const int n = n0 + c8 * 4;
     f32x4 ex[2][PF];
     auto src_of = [&](int m) -> const float* {
@@ -214,10 +238,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     int tm, tn;
     tile_coords(TIC_BID_X, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn, p.gm > 0 ? p.gm : 8);
     const int m0 = tm * 256, n0 = tn * 256;
+    G256_STAMP(0);
+    G256_STAMP_ID();
 #ifndef TIC_SIM
     // experiment: delay every other workgroup of the first wave of tiles so that epilogues (HBM bursts) of one half of the
     // CUs fall into the main loops of the other half
-    if (p.stagger > 0 && TIC_BID_X < 256 && ((TIC_BID_X >> 3) & 1))
+    if (p.stagger > 0 && TIC_BID_X < 256 && ((TIC_BID_X >> 3) & 1))   // the host zeroes it for epilogues outside "gemm_stagger_mask"
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
     const tic_rsrc_t ra = make_rsrc(p.A, (uint32_t)((size_t)p.M * p.K * 2));
@@ -391,6 +417,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     load_b(0u, 0, fbx);
     wait_lgkmcnt0();
     if (wr == 1 && !(DBG & 16)) g256_barrier();
+    G256_STAMP(1);
 
     // two tiles per trip (the B register sets swap roles every tile); an odd tile count runs one extra all-zero tile
     // (its DMAs are the zero fills above) rather than a second loop exit, which made hipcc copy all 128 accumulators
@@ -399,34 +426,46 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         tile(kt, fbx, fby);
         tile(kt + 1, fby, fbx);
     }
+    G256_STAMP(2);
     wait_vmcnt0();   // drain the zero fills issued for the tiles past the end before LDS is reused
+    // the extra operand tile of the DGELU / MULAUX epilogues: every row of it in flight from here (see g256_fetch_aux)
+    // from here on the thread index is re-derived from the hardware: threadIdx-derived registers need not survive the K loop
+    const int le = lane_id_fresh(), tide = w * 64 + le;
+    u32x4 auxr[16];
+    if (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX) {
+        if (p.nt & 2) g256_fetch_aux<true, 0, G256_AUX_EARLY>(p, tide, m0, n0, auxr);
+        else g256_fetch_aux<false, 0, G256_AUX_EARLY>(p, tide, m0, n0, auxr);
+        sched_fence();
+    }
     if (wr == 0 && !(DBG & 16)) g256_barrier();   // re-balance the stagger
     g256_barrier();                // every wave's LDS reads and DMA writes have retired: the tile buffers are free
 
     // ---- stage u = bf16(acc) into LDS: rows r = i*4 + mt, column groups g = j*2 + nt
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int col = (g >> 1) * 128 + wc * 32 + (g & 1) * 16 + 4 * (l >> 4);
+        const int col = (g >> 1) * 128 + wc * 32 + (g & 1) * 16 + 4 * (le >> 4);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int row = (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (l & 15);
+            const int row = (r >> 2) * 128 + wr * 64 + (r & 3) * 16 + (le & 15);
             const f32x4 v = acc[r >> 2][g >> 1][r & 3][g & 1];
             lds_st64(g256_stage_off(row, col >> 2), __builtin_bit_cast(bf16x4, u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])}));
         }
     }
     block_sync();
+    G256_STAMP(3);
     sched_fence();   // keep the second pass (and its operand prefetch) below the staging pass: the accumulators are dead from here
     // kernel-argument (block-uniform) choice of the cache policy of the second pass
-#define G256_FINISH(FN)                                                   \
+#define G256_FINISH(FN, ...)                                              \
     do {                                                                  \
-        if (p.nt == 0) FN<EPI, false, false>(p, m0, n0);                  \
-        else if (p.nt == 1) FN<EPI, true, false>(p, m0, n0);              \
-        else if (p.nt == 2) FN<EPI, false, true>(p, m0, n0);              \
-        else FN<EPI, true, true>(p, m0, n0);                              \
+        if (p.nt == 0) FN<EPI, false, false>(p, tide, m0, n0, ##__VA_ARGS__);   \
+        else if (p.nt == 1) FN<EPI, true, false>(p, tide, m0, n0, ##__VA_ARGS__);  \
+        else if (p.nt == 2) FN<EPI, false, true>(p, tide, m0, n0, ##__VA_ARGS__);  \
+        else FN<EPI, true, true>(p, tide, m0, n0, ##__VA_ARGS__);               \
     } while (0)
     if (EPI == TIC_EPI_RESID || EPI == TIC_EPI_PATCH)
         G256_FINISH(g256_finish_f32);
     else
-        G256_FINISH(g256_finish_bf16);
+        G256_FINISH(g256_finish_bf16, auxr);
 #undef G256_FINISH
+    G256_STAMP(4);
 }

@@ -52,7 +52,25 @@ static int g_opt_ln_blocks = 4096;   // grid cap of the LayerNorm kernels (4 row
 static int g_opt_gemm_gm = 8;
 static int g_opt_attn_fwd_waves = 8;   // attention forward: waves per (image, head) workgroup, 4 or 8 (two workgroups per CU either way; 8: 179 -> 150 us)
 static int g_opt_tn_main_bias = 0;   // extra M steps given to the 'main' workgroups of the phase-aligned stream-K split (tail ones pay 3 prologues / epilogues)
-static int g_opt_gemm_dbg = 0;
+#ifdef TIC_MEASURE
+static int g_opt_gemm_dbg = 0;                   // measurement build (libtic_hip_dbg.so) only
+static unsigned long long* g_dbg_stamps = nullptr;   // device buffer [grid][8] for the stage stamps of ONE 256x256 NT launch
+static int g_dbg_stamp_at = -1, g_dbg_nt_launches = 0;
+static int g_dbg_log[4096][4];                       // (epilogue, M, N, K) of the 256x256 NT launches since the last reset
+// stamps go to dev_ptr for the launch_index-th 256x256 NT launch after this call (-1: every launch); also resets the launch log
+extern "C" int tic_dbg_set_stamp_buffer(void* dev_ptr, int launch_index) {
+    g_dbg_stamps = (unsigned long long*)dev_ptr;
+    g_dbg_stamp_at = launch_index;
+    g_dbg_nt_launches = 0;
+    return TIC_OK;
+}
+extern "C" int tic_dbg_launch_log(int i, int* out4) {
+    if (i < 0 || i >= g_dbg_nt_launches || i >= 4096) return TIC_EINVAL;
+    for (int j = 0; j < 4; ++j) out4[j] = g_dbg_log[i][j];
+    return TIC_OK;
+}
+#endif
+static int g_opt_gemm_stagger_mask = 0x7f;   // bit e: apply "gemm_stagger" to epilogue e
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
 static int g_opt_tn_mfma = 16;    // grouped dW stream-K launch on v_mfma_f32_16x16x32_bf16 (default) or 32x32x16 (A/B)
@@ -78,14 +96,20 @@ extern "C" int tic_set_option(const char* name, int value) {
         g_opt_nt = value;
         return TIC_OK;
     }
+    if (name && !strcmp(name, "gemm_stagger_mask") && value >= 0 && value < 128) {
+        g_opt_gemm_stagger_mask = value;
+        return TIC_OK;
+    }
     if (name && !strcmp(name, "gemm_stagger") && value >= -1 && value <= 64) {
         g_opt_gemm_stagger = value;
         return TIC_OK;
     }
-    if (name && !strcmp(name, "gemm_dbg") && value >= 0 && value < 32) {
+#ifdef TIC_MEASURE
+    if (name && !strcmp(name, "gemm_dbg") && value >= 0 && value < 32) {   // measurement build only: garbage results by construction
         g_opt_gemm_dbg = value;
         return TIC_OK;
     }
+#endif
     if (name && !strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) {
         g_opt_gemm_tile = value;
         return TIC_OK;
@@ -154,9 +178,20 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     // chip alternate between epilogue and main loop.  Stand-alone back-to-back launches of fc1+GELU gain 11 %
     // (tools/stagger_probe.py); inside the training step the gain is zero (tools/ab_step.py gemm_stagger 0 2: 141.8 vs
     // 141.9 ms) -- there the previous kernel's tail already starts the CUs at different times.
-    p.stagger = g_opt_gemm_stagger > 0 ? g_opt_gemm_stagger : 0;
+    p.stagger = (g_opt_gemm_stagger > 0 && ((g_opt_gemm_stagger_mask >> epilogue) & 1)) ? g_opt_gemm_stagger : 0;
     p.nt = (g_opt_nt >> 2) & 3;
     p.gm = g_opt_gemm_gm;
+#ifdef TIC_MEASURE
+    p.stamps = nullptr;
+    if (big) {
+        if (g_dbg_stamps && (g_dbg_stamp_at < 0 || g_dbg_stamp_at == g_dbg_nt_launches)) p.stamps = g_dbg_stamps;
+        if (g_dbg_nt_launches < 4096) {
+            g_dbg_log[g_dbg_nt_launches][0] = epilogue; g_dbg_log[g_dbg_nt_launches][1] = M;
+            g_dbg_log[g_dbg_nt_launches][2] = N; g_dbg_log[g_dbg_nt_launches][3] = K;
+        }
+        ++g_dbg_nt_launches;
+    }
+#endif
 #define TIC_GEMM_NT_LAUNCH(E)                                                                        \
     do {                                                                                             \
         if (big) {                                                                                   \
@@ -170,6 +205,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     switch (epilogue) {
         case TIC_EPI_BF16:
             TIC_REQUIRE(out_bf16, "gemm_nt: EPI_BF16 needs out_bf16");
+#ifdef TIC_MEASURE
             if (big && g_opt_gemm_dbg) {
 #define TIC_DBG_CASE(D)                                                                                   \
     case D:                                                                                               \
@@ -183,6 +219,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
 #undef TIC_DBG_CASE
                 break;
             }
+#endif
             TIC_GEMM_NT_LAUNCH(TIC_EPI_BF16);
             break;
         case TIC_EPI_GELU:
@@ -306,6 +343,7 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
             TIC_RT_TIMER_MARK(1, stream);
             return tic_after_launch("gemm_tn_group(stream-K)");
         }
+#ifdef TIC_MEASURE
         if (g_opt_gemm_dbg) {
 #define TIC_DBG_CASE(D)                                                                   \
     case D:                                                                               \
@@ -319,6 +357,7 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
 #undef TIC_DBG_CASE
             return tic_after_launch("gemm_tn_group(dbg)");
         }
+#endif
         TIC_RT_MAX_LDS(gemm_tn256_kernel<0>, G256_LDS_BYTES);
         if (!force256) TIC_RT_TIMER_MARK(0, stream);
         TIC_LAUNCH(gemm_tn256_kernel<0>, t, 512, G256_LDS_BYTES, stream, gp);

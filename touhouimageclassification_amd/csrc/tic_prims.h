@@ -151,6 +151,9 @@ TIC_DEV float wave64_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 TIC_DEV int lane_id() { return threadIdx.x & 63; }
+// the lane index re-derived from the hardware (2 VALU instructions): used by code that runs AFTER a register-starved main loop, so
+// that threadIdx-derived values need not stay live (hipcc spilled them to scratch rather than recomputing them)
+TIC_DEV int lane_id_fresh() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 TIC_DEV int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 TIC_DEV uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
