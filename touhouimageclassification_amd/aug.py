@@ -47,62 +47,82 @@ def preset_name(enable_augmentation: bool, enable_diversity: bool, enable_genera
     raise Exception("Must select diversity or generalization!")   # ntrain.py:130
 
 
-def _resized_crop_box(H: int, W: int, g: torch.Generator, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
-    area = H * W
-    lr = (math.log(ratio[0]), math.log(ratio[1]))
-    for _ in range(10):
-        target = area * torch.empty(1).uniform_(scale[0], scale[1], generator=g).item()
-        ar = math.exp(torch.empty(1).uniform_(lr[0], lr[1], generator=g).item())
-        w, h = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
-        if 0 < w <= W and 0 < h <= H:
-            return (int(torch.randint(0, H - h + 1, (1,), generator=g).item()), int(torch.randint(0, W - w + 1, (1,), generator=g).item()), h, w)
-    in_ratio = W / H
+def _uniform(g, shape, lo=0.0, hi=1.0) -> torch.Tensor:
+    return torch.empty(shape).uniform_(lo, hi, generator=g)
+
+
+def _first_valid(ok: torch.Tensor):
+    """ok [B, T] bool -> (index of the first True per row (0 if none), any True per row): the 'try up to T times' loops of
+    torchvision's get_params, for a whole batch at once"""
+    return ok.to(torch.int8).argmax(dim=1), ok.any(dim=1)
+
+
+def _resized_crop_boxes(B: int, H: int, W: int, g, scale=(0.08, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0), tries: int = 10):
+    """RandomResizedCrop.get_params for B images: up to 10 (area, log-uniform aspect) draws each, the first that fits wins, else
+    the central crop clamped to the ratio range.  -> top, left, h, w as fp32 [B]"""
+    area = float(H * W)
+    target = area * _uniform(g, (B, tries), scale[0], scale[1])
+    ar = torch.exp(_uniform(g, (B, tries), math.log(ratio[0]), math.log(ratio[1])))
+    w, h = torch.round(torch.sqrt(target * ar)), torch.round(torch.sqrt(target / ar))
+    first, found = _first_valid((w > 0) & (w <= W) & (h > 0) & (h <= H))
+    rows = torch.arange(B)
+    h, w = h[rows, first], w[rows, first]
+    in_ratio = W / H   # fallback: whole image, clamped to the aspect range
     if in_ratio < ratio[0]:
-        w, h = W, int(round(W / ratio[0]))
+        fw, fh = W, int(round(W / ratio[0]))
     elif in_ratio > ratio[1]:
-        h, w = H, int(round(H * ratio[1]))
+        fh, fw = H, int(round(H * ratio[1]))
     else:
-        w, h = W, H
-    return (H - h) // 2, (W - w) // 2, h, w
+        fw, fh = W, H
+    h, w = torch.where(found, h, torch.tensor(float(fh))), torch.where(found, w, torch.tensor(float(fw)))
+    top = torch.minimum(torch.floor(_uniform(g, (B,)) * (H - h + 1)), H - h)      # randint(0, H - h + 1)
+    left = torch.minimum(torch.floor(_uniform(g, (B,)) * (W - w + 1)), W - w)
+    top = torch.where(found, top, torch.tensor(float((H - fh) // 2)))
+    left = torch.where(found, left, torch.tensor(float((W - fw) // 2)))
+    return top, left, h, w
 
 
-def _erase_box(S: int, g: torch.Generator, p: float, scale=(0.02, 0.33), ratio=(0.3, 3.3)):
-    if p <= 0 or torch.rand(1, generator=g).item() >= p:
-        return None
-    area = S * S
-    lr = (math.log(ratio[0]), math.log(ratio[1]))
-    for _ in range(10):
-        ea = area * torch.empty(1).uniform_(scale[0], scale[1], generator=g).item()
-        ar = math.exp(torch.empty(1).uniform_(lr[0], lr[1], generator=g).item())
-        h, w = int(round(math.sqrt(ea * ar))), int(round(math.sqrt(ea / ar)))
-        if h < S and w < S:
-            return (int(torch.randint(0, S - h + 1, (1,), generator=g).item()), int(torch.randint(0, S - w + 1, (1,), generator=g).item()), h, w)
-    return None
+def _erase_boxes(B: int, S: int, g, p: float, scale=(0.02, 0.33), ratio=(0.3, 3.3), tries: int = 10):
+    """RandomErasing.get_params for B images -> (erase flag, top, left, h, w) fp32 [B]; an image whose 10 draws all miss keeps no box"""
+    if p <= 0:
+        z = torch.zeros(B)
+        return z, z, z, z, z
+    chosen = _uniform(g, (B,)) < p
+    area = float(S * S)
+    ea = area * _uniform(g, (B, tries), scale[0], scale[1])
+    ar = torch.exp(_uniform(g, (B, tries), math.log(ratio[0]), math.log(ratio[1])))
+    h, w = torch.round(torch.sqrt(ea * ar)), torch.round(torch.sqrt(ea / ar))
+    first, found = _first_valid((h < S) & (w < S))
+    rows = torch.arange(B)
+    h, w = h[rows, first], w[rows, first]
+    top = torch.minimum(torch.floor(_uniform(g, (B,)) * (S - h + 1)), S - h)
+    left = torch.minimum(torch.floor(_uniform(g, (B,)) * (S - w + 1)), S - w)
+    on = (chosen & found).float()
+    return on, top * on, left * on, h * on, w * on
 
 
 def sample_params(B: int, H: int, W: int, S: int, preset: str, generator: Optional[torch.Generator] = None) -> torch.Tensor:
-    """[B, 20] fp32 parameter table (CPU) for `tic_augment`."""
+    """[B, 20] fp32 parameter table (CPU) for `tic_augment`.  One batched draw per parameter -- a few dozen torch calls per BATCH and
+    no host round trip per image (the per-image loop of round 1 made ~15 `.item()` calls per image: 5 000 per 332-image step)."""
     crop, flip, jitter, gray_p, erase_p = PRESETS[preset]
-    g = generator or torch.default_generator
+    g = generator
     P = torch.zeros(B, NPARAM)
-    for b in range(B):
-        top, left, h, w = _resized_crop_box(H, W, g) if crop else (0, 0, H, W)
-        P[b, 0:4] = torch.tensor([top, left, h, w], dtype=torch.float32)
-        P[b, 4] = float(flip and torch.rand(1, generator=g).item() < 0.5)
-        P[b, 5:9] = torch.arange(4, dtype=torch.float32)
-        P[b, 9:12] = 1.0
-        if jitter:
-            P[b, 5:9] = torch.randperm(4, generator=g).float()
-            P[b, 9] = torch.empty(1).uniform_(0.8, 1.2, generator=g).item()
-            P[b, 10] = torch.empty(1).uniform_(0.8, 1.2, generator=g).item()
-            P[b, 11] = torch.empty(1).uniform_(0.8, 1.2, generator=g).item()
-            P[b, 12] = torch.empty(1).uniform_(-0.1, 0.1, generator=g).item()
-            P[b, 13] = 1.0
-        P[b, 14] = float(gray_p > 0 and torch.rand(1, generator=g).item() < gray_p)
-        box = _erase_box(S, g, erase_p)
-        if box is not None:
-            P[b, 15] = 1.0
-            P[b, 16:20] = torch.tensor(box, dtype=torch.float32)
+    if crop:
+        P[:, 0], P[:, 1], P[:, 2], P[:, 3] = _resized_crop_boxes(B, H, W, g)
+    else:
+        P[:, 2], P[:, 3] = float(H), float(W)
+    if flip:
+        P[:, 4] = (_uniform(g, (B,)) < 0.5).float()
+    P[:, 5:9] = torch.arange(4, dtype=torch.float32)
+    P[:, 9:12] = 1.0
+    if jitter:
+        P[:, 5:9] = torch.argsort(_uniform(g, (B, 4)), dim=1).float()      # a uniformly random order of the four colour ops
+        P[:, 9:12] = _uniform(g, (B, 3), 0.8, 1.2)                          # brightness, contrast, saturation factors
+        P[:, 12] = _uniform(g, (B,), -0.1, 0.1)                             # hue shift
+        P[:, 13] = 1.0
+    if gray_p > 0:
+        P[:, 14] = (_uniform(g, (B,)) < gray_p).float()
+    P[:, 15], P[:, 16], P[:, 17], P[:, 18], P[:, 19] = _erase_boxes(B, S, g, erase_p)
     return P
 
 
