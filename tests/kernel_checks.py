@@ -242,21 +242,19 @@ def check_gemm_tn_group(env, M, shapes):
         torch.testing.assert_close(c, r, atol=2e-3 * max(1.0, (M / 200) ** 0.5), rtol=1e-3)
 
 
-def check_augment(env, S=32, H=40, W=48):
-    """HIP augmentation vs the float CPU restatement (oracle/aug_oracle.py) for explicit parameters"""
+def aug_cases(H, W):
     from oracle import aug_oracle as ao
-    import ctypes
-    dev, call = env.dev, env.call
-    g = torch.Generator().manual_seed(5)
-    cases = [
+    return [
         ao.AugParams(0, 0, H, W, jitter=False),                                                     # plain Resize (val/test)
         ao.AugParams(3, 5, 30, 20, flip=True, order=(2, 0, 3, 1), brightness=1.15, contrast=0.85, saturation=1.1, hue=0.07, gray=False, erase=(4, 6, 10, 9)),
         ao.AugParams(10, 0, 17, 48, flip=False, order=(1, 3, 0, 2), brightness=0.8, contrast=1.2, saturation=0.8, hue=-0.1, gray=True),
         ao.AugParams(0, 8, 40, 33, flip=True, order=(3, 2, 1, 0), brightness=1.0, contrast=1.19, saturation=1.2, hue=0.0, erase=(0, 0, 31, 5)),
     ]
-    B = len(cases)
-    imgs = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
-    P = torch.zeros(B, 20)
+
+
+def aug_param_table(cases):
+    """explicit AugParams -> the [B, 20] fp32 rows tic_augment takes"""
+    P = torch.zeros(len(cases), 20)
     for b, c in enumerate(cases):
         P[b, 0:4] = torch.tensor([c.top, c.left, c.height, c.width], dtype=torch.float32)
         P[b, 4] = float(c.flip)
@@ -266,6 +264,32 @@ def check_augment(env, S=32, H=40, W=48):
         if c.erase is not None:
             P[b, 15] = 1.0
             P[b, 16:20] = torch.tensor(c.erase, dtype=torch.float32)
+    return P
+
+
+def _aug_close(out, ref, b):
+    # hue is discontinuous at sector boundaries: allow a few outlier pixels there, everything else tight
+    diff = (out - ref).abs()
+    assert diff.median() < 1e-5 and (diff > 2e-3).float().mean() < 2e-3, (b, diff.max().item(), (diff > 2e-3).float().mean().item())
+
+
+def check_augment(env, S=32, H=40, W=48):
+    """HIP augmentation vs the float CPU restatement (oracle/aug_oracle.py) for explicit parameters, and -- at the fixture size --
+    vs the committed vectors of tests/golden/aug_cases.npz (inputs + expected outputs: the oracle cannot drift unnoticed)"""
+    from oracle import aug_oracle as ao
+    import ctypes
+    import os
+    import numpy as np
+    dev, call = env.dev, env.call
+    g = torch.Generator().manual_seed(5)
+    cases = aug_cases(H, W)
+    B = len(cases)
+    imgs = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    P = aug_param_table(cases)
+    gold_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aug_cases.npz")
+    gold = np.load(gold_path) if (S, H, W) == (32, 40, 48) else None
+    if gold is not None:
+        assert np.array_equal(gold["imgs"], imgs.numpy()) and np.array_equal(gold["params"], P.numpy())
     out = torch.empty(B, 3, S, S, device=dev)
     mean = (ctypes.c_float * 3)(*ao.IMAGENET_MEAN)
     std = (ctypes.c_float * 3)(*ao.IMAGENET_STD)
@@ -273,9 +297,10 @@ def check_augment(env, S=32, H=40, W=48):
     call("tic_augment", ptr(imgs_d), B, H, W, ptr(P_d), ptr(out), S, mean, std, None)
     for b, c in enumerate(cases):
         ref = ao.augment_one(imgs[b], c, out=S)
-        # hue is discontinuous at sector boundaries: allow a few outlier pixels there, everything else tight
-        diff = (out[b].cpu() - ref).abs()
-        assert diff.median() < 1e-5 and (diff > 2e-3).float().mean() < 2e-3, (b, diff.max().item(), (diff > 2e-3).float().mean().item())
+        _aug_close(out[b].cpu(), ref, b)
+        if gold is not None:
+            torch.testing.assert_close(ref, torch.from_numpy(gold["out"][b]), atol=1e-6, rtol=1e-6)   # oracle == committed vector
+            _aug_close(out[b].cpu(), torch.from_numpy(gold["out"][b]), b)                              # HIP == committed vector
 
 
 def check_mix(env):
@@ -298,6 +323,22 @@ def check_mix(env):
     lam_adj = 1.0 - (x2 - x1) * (y2 - y1) / float(W * H)
     call("tic_mix_labels", ptr(y), ptr(soft), B, ncls, lam_adj, None)
     torch.testing.assert_close(soft.cpu(), ry_)
+    # the committed vectors (tests/golden/aug_cases.npz): HIP on the fixture inputs == the fixture outputs
+    import os
+    import numpy as np
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aug_cases.npz"))
+    gx, gy = torch.from_numpy(gold["mix_x"]).to(dev), torch.from_numpy(gold["mix_y"]).to(dev)
+    gout, gsoft = torch.empty_like(gx), torch.empty(B, ncls, device=dev)
+    call("tic_mix", ptr(gx), ptr(gout), B, C, H, W, 0, 0.3, 0, 0, 0, 0, None)
+    call("tic_mix_labels", ptr(gy), ptr(gsoft), B, ncls, 0.3, None)
+    torch.testing.assert_close(gout.cpu(), torch.from_numpy(gold["mixup_x"]))
+    torch.testing.assert_close(gsoft.cpu(), torch.from_numpy(gold["mixup_y"]))
+    bx1, by1, bx2, by2 = (int(v) for v in gold["cutmix_box"])
+    assert (bx1, by1, bx2, by2) == (x1, y1, x2, y2)
+    call("tic_mix", ptr(gx), ptr(gout), B, C, H, W, 1, 0.0, bx1, by1, bx2, by2, None)
+    call("tic_mix_labels", ptr(gy), ptr(gsoft), B, ncls, lam_adj, None)
+    assert torch.equal(gout.cpu(), torch.from_numpy(gold["cutmix_x"]))
+    torch.testing.assert_close(gsoft.cpu(), torch.from_numpy(gold["cutmix_y"]))
 
 
 def check_fused_bias_gradients(env):

@@ -112,7 +112,15 @@ def gen_resnet():
     sys.path.insert(0, "/root/reference")
     from TIC.ResNet import model as ref   # reference file, torch only
     from oracle import resnet_oracle as ro
-    for name, B, C, img in (("resnet18", 4, 10, 64), ("resnet50", 8, 10, 224)):
+    # the *_b32 / resnet152 cases (round 2): 32 images give BatchNorm well-conditioned batch statistics, so the GPU test can hold
+    # FIXED tolerances against them (the two small-batch files keep the self-scaling comparison they were written for);
+    # resnet152 @256 px is the configuration the reference itself trains (TIC/ResNet/train.py:210-255)
+    cases = (("resnet18", "resnet18", 4, 10, 64), ("resnet50", "resnet50", 8, 10, 224), ("resnet18_b32", "resnet18", 32, 10, 64),
+             ("resnet50_b32", "resnet50", 32, 10, 128), ("resnet152_b8", "resnet152", 8, 10, 256))
+    only = os.environ.get("TIC_GOLDEN_ONLY")
+    for tag, name, B, C, img in cases:
+        if only and tag not in only.split(","):
+            continue
         sd = ro.init_state(name, C, seed=3)
         g = torch.Generator().manual_seed(7)
         for k in sd:   # non-trivial BN affine / running stats so those paths are exercised
@@ -132,7 +140,7 @@ def gen_resnet():
         err = (logits.detach() - o_logits).abs().max().item()
         gerr = max((grads[k] - o_grads[k]).norm().item() / (grads[k].norm().item() + 1e-30) for k in grads)
         rerr = max((after[k].double() - o_after[k].double()).abs().max().item() for k in after)
-        print(f"[{name}] oracle-vs-reference (fp64) logits max|d|={err:.2e} grads rel={gerr:.2e} running-stats d={rerr:.2e}")
+        print(f"[{tag}] oracle-vs-reference (fp64) logits max|d|={err:.2e} grads rel={gerr:.2e} running-stats d={rerr:.2e}")
         assert err < 1e-9 and gerr < 1e-8 and rerr < 1e-10
         assert list(sd.keys()) == list(m.state_dict().keys()), "state_dict key order differs from the reference"
         # the fp32 oracle against this fp64 truth, for the record (what a correct fp32 implementation achieves)
@@ -147,7 +155,29 @@ def gen_resnet():
             out[f"after/{k}"] = v.numpy()
         for k in ("conv1.weight", "fc.weight", "fc.bias", "bn1.weight", "layer1.0.conv1.weight"):
             out[f"grad/{k}"] = grads[k].numpy().astype(np.float32)
-        np.savez_compressed(os.path.join(GOLD, f"{name}.npz"), **out)
+        np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
+
+
+def gen_aug():
+    """Augmentation / MixUp / CutMix: PARITY UNPINNED (torchvision is absent, the reference holds no fixture) -- these vectors are the
+    oracle's own outputs for explicit parameters, committed as DATA so that the restatement cannot drift unnoticed: inputs (uint8
+    images, the 20-column parameter rows, labels) and expected outputs."""
+    from oracle import aug_oracle as ao
+    from tests import kernel_checks as kc
+    H, W, S = 40, 48, 32
+    cases = kc.aug_cases(H, W)
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randint(0, 256, (len(cases), H, W, 3), generator=g, dtype=torch.uint8)
+    out = torch.stack([ao.augment_one(imgs[b], c, out=S) for b, c in enumerate(cases)])
+    g2 = torch.Generator().manual_seed(9)
+    x = torch.randn(5, 3, 16, 24, generator=g2)
+    y = torch.randint(0, 7, (5,), generator=g2)
+    mx, my = ao.mixup(x, y, 7, 0.3)
+    cx, cy = ao.cutmix(x, y, 7, 0.4, 17, 5)
+    np.savez_compressed(os.path.join(GOLD, "aug_cases.npz"), H=H, W=W, S=S, imgs=imgs.numpy(), params=kc.aug_param_table(cases).numpy(),
+                        out=out.numpy(), mix_x=x.numpy(), mix_y=y.numpy(), mixup_x=mx.numpy(), mixup_y=my.numpy(),
+                        cutmix_x=cx.numpy(), cutmix_y=cy.numpy(), cutmix_box=np.array(ao.cutmix_box(16, 24, 0.4, 17, 5)))
+    print("[aug] explicit-parameter vectors written (oracle self-pinned; parity with torchvision remains unpinned)")
 
 
 if __name__ == "__main__":
@@ -159,3 +189,5 @@ if __name__ == "__main__":
         gen_vit_full("large_c120_b2", vo.VIT_LARGE, 120, 2, seed=20)
     if what in ("resnet", "all"):
         gen_resnet()
+    if what in ("aug", "all"):
+        gen_aug()

@@ -21,6 +21,7 @@ struct GemmTnProblem {
     float* C;          // [N, K]
     int N, K;
     int tile_start;    // first tile index of this problem inside the launch
+    int bw;            // tile-walk block width along the LONGER tile dimension (see tn_tile_lookup), >= 1
 };
 struct GemmTnGroupParams {
     GemmTnProblem prob[TN_MAX_GROUP];
@@ -39,9 +40,23 @@ TIC_DEV void tn_tile_lookup(const GemmTnGroupParams& gp, int tile, const bf16_t*
         if (pi == g) {
             Ap = gp.prob[g].A; Bp = gp.prob[g].B; Cp = gp.prob[g].C; N = gp.prob[g].N; K = gp.prob[g].K; t0 = gp.prob[g].tile_start;
         }
-    const int tiles_k = K / 256, lt = tile - t0;
-    n0 = (lt / tiles_k) * 256;
-    k0 = (lt % tiles_k) * 256;
+    // Tile walk inside a problem: blocks of (short dimension) x bw tiles, so that the ~24 consecutive tiles an XCD takes share few
+    // operand panels (a 4 x 6 block reads 4 + 6 panels; 24 tiles of a row-major walk over a 4 x 16 grid read 2 + 16).  Every A
+    // panel (256 columns of dY) is streamed by all tiles of its tile row, every B panel (256 columns of X) by all tiles of its tile
+    // column; the XCD's L2 serves the repeats only while the co-running tiles share them.  Any bijection is correct; this one is speed.
+    const int tiles_k = K / 256, tiles_n = N / 256, lt = tile - t0;
+    int bwv = gp.prob[0].bw;
+#pragma unroll
+    for (int g = 1; g < TN_MAX_GROUP; ++g)
+        if (pi == g) bwv = gp.prob[g].bw;
+    const bool long_k = tiles_k >= tiles_n;
+    const int ls = long_k ? tiles_n : tiles_k, ll = long_k ? tiles_k : tiles_n;   // short / long tile counts
+    const int blk = lt / (ls * bwv);                       // full blocks first; the last one may be narrower
+    const int w_eff = (ll - blk * bwv < bwv) ? (ll - blk * bwv) : bwv;
+    const int r = lt - blk * ls * bwv;
+    const int s_idx = r / w_eff, l_idx = blk * bwv + (r - s_idx * w_eff);
+    n0 = (long_k ? s_idx : l_idx) * 256;
+    k0 = (long_k ? l_idx : s_idx) * 256;
 }
 
 // One 256x256 output tile (origin n0, k0 of problem A/B/C) over the M steps [step0, step1) of 64 rows.

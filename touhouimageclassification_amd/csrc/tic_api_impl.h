@@ -73,6 +73,7 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
 static int g_opt_gemm_stagger_mask = 0x7f;   // bit e: apply "gemm_stagger" to epilogue e
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
+static int g_opt_tn_block = -1;   // tile-walk block width of the grouped dW launch: -1 auto (one XCD share per block), 0 row-major, n fixed
 static int g_opt_tn_mfma = 16;    // grouped dW stream-K launch on v_mfma_f32_16x16x32_bf16 (default) or 32x32x16 (A/B)
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 extern "C" int tic_set_option(const char* name, int value) {
@@ -112,6 +113,10 @@ extern "C" int tic_set_option(const char* name, int value) {
 #endif
     if (name && !strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) {
         g_opt_gemm_tile = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "tn_block") && value >= -1 && value <= 64) {
+        g_opt_tn_block = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "tn_mfma") && (value == 16 || value == 32)) {
@@ -306,11 +311,26 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
     if (ok256 && g_opt_gemm_tile != 128 && (force256 || g_opt_gemm_tile == 256 || (tiles >= 96 && M >= 2048))) {
         GemmTnGroupParams gp;
         memset(&gp, 0, sizeof(gp));
+        // launch order of the problems: those whose tile count is a whole number of XCD shares (tiles / 8 each) first, so that their
+        // blocks line up with the XCD boundaries of the tile walk; then the rest
+        int order[TN_MAX_GROUP], no = 0;
+        const int per_xcd = tiles >= 8 ? tiles / 8 : tiles;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int g = 0; g < nprob; ++g) {
+                const bool whole = ((N[g] / 256) * (K[g] / 256)) % per_xcd == 0;
+                if (whole == (pass == 0)) order[no++] = g;
+            }
         int t = 0;
-        for (int g = 0; g < nprob; ++g) {
-            gp.prob[g].A = (const bf16_t*)A[g]; gp.prob[g].B = (const bf16_t*)B[g]; gp.prob[g].C = C[g];
-            gp.prob[g].N = N[g]; gp.prob[g].K = K[g]; gp.prob[g].tile_start = t;
-            t += (N[g] / 256) * (K[g] / 256);
+        for (int i = 0; i < nprob; ++i) {
+            const int g = order[i];
+            gp.prob[i].A = (const bf16_t*)A[g]; gp.prob[i].B = (const bf16_t*)B[g]; gp.prob[i].C = C[g];
+            gp.prob[i].N = N[g]; gp.prob[i].K = K[g]; gp.prob[i].tile_start = t;
+            const int tn_ = N[g] / 256, tk_ = K[g] / 256, ls = tn_ < tk_ ? tn_ : tk_;
+            int bw = g_opt_tn_block >= 0 ? g_opt_tn_block : (per_xcd + ls / 2) / ls;   // (short dimension) x bw ~ one XCD's share
+            if (bw < 1) bw = 1;
+            if (g_opt_tn_block == 0) bw = tn_ < tk_ ? tk_ : tn_;                        // 0: the plain row-major walk (A/B)
+            gp.prob[i].bw = bw;
+            t += tn_ * tk_;
         }
         gp.nprob = nprob; gp.M = M; gp.total_tiles = t;
         const int nsteps = (M + 63) / 64;
