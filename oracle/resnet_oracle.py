@@ -99,6 +99,18 @@ def init_state(name: str, num_classes: int, seed: int = 0) -> Dict[str, torch.Te
     return st
 
 
+# residual gains of the well-conditioned golden cases (tools/gen_golden.py, tests/resnet_checks.py): deeper nets need smaller ones
+GOLDEN_RESIDUAL_GAIN = {"resnet18_b32": 0.25, "resnet50_b32": 0.25, "resnet152_b8": 0.1}
+
+
+def damp_residual_gains(st: Dict[str, torch.Tensor], name: str, gain: float) -> None:
+    """scale the weight of the LAST BatchNorm of every residual branch (bn3 of a Bottleneck, bn2 of a BasicBlock) in place:
+    gain 0 is the reference's ``zero_init_residual`` option (TIC/ResNet/model.py:178-183), 1 its default init"""
+    plan, _ = block_plan(name)
+    for p, kind, *_ in plan:
+        st[p + (".bn2.weight" if kind == "basic" else ".bn3.weight")].mul_(gain)
+
+
 def is_param(key: str) -> bool:
     return not (key.endswith("running_mean") or key.endswith("running_var") or key.endswith("num_batches_tracked"))
 

@@ -452,3 +452,41 @@ def check_moe_ops(env, B=7, E=8, K=2, C=120):
         torch.testing.assert_close(loss3.cpu()[2], mo.load_balance_loss(g.cpu()), atol=1e-6, rtol=1e-5)
         torch.testing.assert_close(dz.cpu(), zr.grad, atol=1e-6, rtol=1e-4)
         torch.testing.assert_close(dg.cpu(), gr.grad, atol=1e-7, rtol=1e-4)
+
+
+def check_persistent_nt_matches(env, M, N, K, pgrid):
+    """the persistent 256x256 NT kernel (gemm256p.h: one workgroup walks several tiles, the next tile's operands prefetched under
+    the second pass) against the one-tile-per-workgroup kernel: same fp32 accumulation order, so every epilogue it serves must be
+    BIT-identical, column sums included (those only up to the order of their atomics)"""
+    rnd, call, dev = env.rnd, env.call, env.dev
+    A, B, bias = bf(rnd(M, K, scale=0.3)), bf(rnd(N, K, scale=0.3)), rnd(N, scale=0.1)
+    aux = bf(rnd(M, N, scale=0.5))
+
+    def run(epi, persist):
+        env._call("tic_set_option", b"gemm_persist", persist)
+        o1 = torch.full((M, N), 3.0, device=dev).to(torch.bfloat16)
+        o2 = torch.full((M, N), 5.0, device=dev).to(torch.bfloat16)
+        cs = torch.zeros(N, device=dev)
+        has_cs = epi in (0, 3, 6)
+        call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), M, N, K, epi, None if epi in (3, 6) else ptr(bias), ptr(o1), ptr(o2) if epi in (1, 5) else None,
+             None, None, ptr(aux) if epi in (3, 6) else None, None, 0, ptr(cs) if has_cs else None, None)
+        return o1, o2, cs
+
+    env._call("tic_set_option", b"gemm_tile", 256)
+    env._call("tic_set_option", b"gemm_pgrid", pgrid)
+    try:
+        for epi in (0, 1, 5, 3, 6):
+            r1, r2, rcs = run(epi, 0)
+            for _ in range(2):
+                p1, p2, pcs = run(epi, 1)
+                assert torch.equal(p1, r1), (epi, "out")
+                if epi in (1, 5):
+                    assert torch.equal(p2, r2), (epi, "out2")
+                if epi in (0, 3, 6):
+                    torch.testing.assert_close(pcs, rcs, atol=1e-3 * max(1.0, float(rcs.abs().max())), rtol=1e-4)
+        ref = A.float() @ B.float().t() + bias           # and the plain epilogue against fp32 math
+        torch.testing.assert_close(run(0, 1)[0].float(), ref, atol=0.06, rtol=0.02)
+    finally:
+        env._call("tic_set_option", b"gemm_tile", 0)
+        env._call("tic_set_option", b"gemm_pgrid", 256)
+        env._call("tic_set_option", b"gemm_persist", 1)

@@ -332,6 +332,7 @@ TIC_DEV void atomic_addf(float* p, float v) { *p += v; }
 TIC_DEV float fast_exp2(float x) { return exp2f(x); }
 TIC_DEV float fast_rcp(float x) { return 1.0f / x; }
 TIC_DEV void glds16_nt(tic_rsrc_t r, uint32_t lds_off, uint32_t voff, uint32_t soff) { glds16(r, lds_off, voff, soff); }
+TIC_DEV void buf_st128_nt(tic_rsrc_t r, u32x4 v, uint32_t voff, uint32_t soff) { buf_st128(r, v, voff, soff); }
 TIC_DEV float row16_sum(float v) {
     for (int m = 1; m < 16; m <<= 1) v += shfl_xor(v, m);
     return v;

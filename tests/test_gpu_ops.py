@@ -107,3 +107,10 @@ def test_mix(env):
 
 def test_fused_bias_gradients(env):
     kc.check_fused_bias_gradients(env)
+
+
+@pytest.mark.parametrize("M,N,K,pgrid", [(1500, 512, 192, 3), (12608, 1024, 1024, 64), (16351, 4096, 1024, 256), (65404, 3072, 1024, 256), (32702, 1024, 4096, 256)])
+def test_persistent_nt_kernel_is_bit_identical(env, M, N, K, pgrid):
+    """the persistent 256x256 NT kernel at hot-path shapes (several tiles per workgroup, LDS-DMA prefetch of the next tile under the
+    second pass, counted waits stepping over the stores): bit-identical to the one-tile-per-workgroup kernel, launch after launch"""
+    kc.check_persistent_nt_matches(env, M, N, K, pgrid)

@@ -111,3 +111,9 @@ def test_gemm_tn_group_phase_aligned_split(env, mfma):
         call("tic_set_option", b"gemm_tile", 0)
         call("tic_set_option", b"tn_streamk", 1)
         call("tic_set_option", b"tn_mfma", 16)
+
+
+@pytest.mark.parametrize("M,N,K,pgrid", [(600, 512, 192, 2), (300, 256, 128, 1)])
+def test_persistent_nt_kernel_is_bit_identical(env, M, N, K, pgrid):
+    """6 tiles on 2 workgroups (3 each, odd K-tile count -> a zero-fill K tile, ragged last row tile) / 2 tiles on 1 workgroup"""
+    kc.check_persistent_nt_matches(env, M, N, K, pgrid)

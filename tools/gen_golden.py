@@ -126,6 +126,12 @@ def gen_resnet():
         for k in sd:   # non-trivial BN affine / running stats so those paths are exercised
             if sd[k].ndim == 1 and sd[k].is_floating_point() and not k.startswith("fc"):
                 sd[k] = sd[k] + torch.empty_like(sd[k]).normal_(0, 0.05, generator=g)
+        if tag != name:
+            # round-2 cases: "trained-like" residual gains.  A RANDOM-init ResNet is chaotic in its activations (the bf16-rounding
+            # oracle itself lands 0.31 from the fp64 logits of ResNet-50 at B = 32, gradient directions at cos 0.16), so no fixed
+            # tolerance can separate a kernel bug from storage rounding there.  With the last BatchNorm of every residual branch at
+            # gamma ~ 0.25 (0.1 for ResNet-152; between the reference's zero_init_residual option, model.py:178-183, and 1) the map is well conditioned.
+            ro.damp_residual_gains(sd, name, ro.GOLDEN_RESIDUAL_GAIN[tag])
         x = torch.randn(B, 3, img, img, generator=g)
         y = torch.randint(0, C, (B,), generator=g)
         m = getattr(ref, name)(num_classes=C).double().train()

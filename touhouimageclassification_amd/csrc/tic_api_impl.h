@@ -14,6 +14,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "gemm256.h"
+#include "gemm256p.h"
 #include "gemm_tn256.h"
 #include "moe.h"
 #include "norm.h"
@@ -70,6 +71,8 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
     return TIC_OK;
 }
 #endif
+static int g_opt_gemm_persist = 1;      // persistent 256x256 NT kernel (gemm256p.h) where a launch has more tiles than workgroups; 0: never
+static int g_opt_gemm_pgrid = 256;      // its grid: one workgroup per CU (tests shrink it to force several tiles per workgroup)
 static int g_opt_gemm_stagger_mask = 0x7f;   // bit e: apply "gemm_stagger" to epilogue e
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
@@ -95,6 +98,14 @@ extern "C" int tic_set_option(const char* name, int value) {
     }
     if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
         g_opt_nt = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "gemm_persist") && (value == 0 || value == 1)) {
+        g_opt_gemm_persist = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "gemm_pgrid") && value >= 1 && value <= 4096) {
+        g_opt_gemm_pgrid = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "gemm_stagger_mask") && value >= 0 && value < 128) {
@@ -197,6 +208,17 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         ++g_dbg_nt_launches;
     }
 #endif
+    // more tiles than CUs and an epilogue without second-pass loads: one persistent workgroup per CU walks the tiles
+    const bool persist = big && g_opt_gemm_persist && grid > g_opt_gemm_pgrid && ((double)M + 256.0) * N * 2.0 < 4294967296.0;
+#define TIC_GEMM_NT_LAUNCH_P(E)                                                                      \
+    do {                                                                                             \
+        if (persist) {                                                                               \
+            TIC_RT_MAX_LDS(gemm_nt256p_kernel<E>, G256P_LDS_BYTES);                                  \
+            TIC_LAUNCH(gemm_nt256p_kernel<E>, g_opt_gemm_pgrid, 512, G256P_LDS_BYTES, stream, p);    \
+        } else {                                                                                     \
+            TIC_GEMM_NT_LAUNCH(E);                                                                   \
+        }                                                                                            \
+    } while (0)
 #define TIC_GEMM_NT_LAUNCH(E)                                                                        \
     do {                                                                                             \
         if (big) {                                                                                   \
@@ -225,11 +247,11 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
                 break;
             }
 #endif
-            TIC_GEMM_NT_LAUNCH(TIC_EPI_BF16);
+            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_BF16);
             break;
         case TIC_EPI_GELU:
             TIC_REQUIRE(out_bf16 && out2_bf16, "gemm_nt: EPI_GELU needs out_bf16 and out2_bf16");
-            TIC_GEMM_NT_LAUNCH(TIC_EPI_GELU);
+            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_GELU);
             break;
         case TIC_EPI_RESID:
             TIC_REQUIRE(out_f32 && resid, "gemm_nt: EPI_RESID needs out_f32 and resid");
@@ -237,15 +259,15 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
             break;
         case TIC_EPI_DGELU:
             TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_DGELU needs out_bf16 and aux_bf16");
-            TIC_GEMM_NT_LAUNCH(TIC_EPI_DGELU);
+            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_DGELU);
             break;
         case TIC_EPI_GELU_DG:
             TIC_REQUIRE(out_bf16 && out2_bf16, "gemm_nt: EPI_GELU_DG needs out_bf16 and out2_bf16");
-            TIC_GEMM_NT_LAUNCH(TIC_EPI_GELU_DG);
+            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_GELU_DG);
             break;
         case TIC_EPI_MULAUX:
             TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_MULAUX needs out_bf16 and aux_bf16");
-            TIC_GEMM_NT_LAUNCH(TIC_EPI_MULAUX);
+            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_MULAUX);
             break;
         case TIC_EPI_PATCH:
             TIC_REQUIRE(out_f32 && rowtab && patches > 0 && M % patches == 0, "gemm_nt: EPI_PATCH needs out_f32, rowtab, M %% patches == 0");
@@ -255,6 +277,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
             return tic_fail(TIC_EINVAL, "gemm_nt: unknown epilogue %d", epilogue);
     }
 #undef TIC_GEMM_NT_LAUNCH
+#undef TIC_GEMM_NT_LAUNCH_P
     return tic_after_launch("gemm_nt");
 }
 

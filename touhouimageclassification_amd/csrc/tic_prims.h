@@ -100,6 +100,9 @@ TIC_DEV u32x2 buf_ld64(tic_rsrc_t r, uint32_t voff, uint32_t soff) {
 TIC_DEV void buf_st128(tic_rsrc_t r, u32x4 v, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
 }
+TIC_DEV void buf_st128_nt(tic_rsrc_t r, u32x4 v, uint32_t voff, uint32_t soff) {   // non-temporal policy (aux = 2), as glds16_nt
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 2);
+}
 TIC_DEV void buf_st64(tic_rsrc_t r, u32x2 v, uint32_t voff, uint32_t soff) {
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
