@@ -262,21 +262,32 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(GemmNtParams p) {
     issue(tic_ic<1>{}, tic_ic<1>{}, 1, voa0, vob0);
     issue(tic_ic<1>{}, tic_ic<0>{}, 1, voa0, vob0);
 #pragma unroll
-    for (int i = 0; i < N2; ++i) buf_st128(ra, u32x4{0u, 0u, 0u, 0u}, 0xFFFFFFF0u, 0);
+    for (int i = 0; i < N2; ++i) buf_st128(ra, u32x4{0u, 0u, 0u, 0u}, 0xFFFFF000u + 16u * (uint32_t)i, 0);   // DISTINCT offsets: identical stores are merged into one
     issue(tic_ic<1>{}, tic_ic<2>{}, 1, voa0, vob0);
     wait_vmcnt<8 + N2>();
+#if defined(TIC_MEASURE) && !defined(TIC_SIM)
+#define G256P_STAMP(i)                                                                                       \
+    do {                                                                                                     \
+        if (p.stamps && TIC_TID == 0) p.stamps[(size_t)t * 8 + (i)] = __builtin_amdgcn_s_memrealtime();      \
+    } while (0)
+#else
+#define G256P_STAMP(i) do { } while (0)
+#endif
     for (;;) {
+        G256P_STAMP(0);
         g256_barrier();
         load_a(g256p_slot(0, 0), fa0, 0);
         load_b(g256p_slot(0, 1), fbx);
         wait_lgkmcnt0();
         if (wr == 1) g256_barrier();   // the two wave groups run one barrier apart from here on
+        G256P_STAMP(1);
 
 #pragma nounroll
         for (int kt = 0; kt < nk; kt += 2) {
             tile(tic_ic<0>{}, kt == 0, kt, voa0, vob0, fbx, fby);
             tile(tic_ic<1>{}, false, kt + 1, voa0, vob0, fby, fbx);
         }
+        G256P_STAMP(2);
         wait_vmcnt0();   // only zero fills are pending here
 
         // ---- epilogue of tile t, prologue of tile t + gridDim.x ---------------------------------------------------------------
@@ -312,6 +323,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(GemmNtParams p) {
         }
         wait_lgkmcnt0();
         g256_barrier();   // the staged tile is visible; the accumulators are dead
+        G256P_STAMP(3);
         sched_fence();
         if (HAS_AUX) {
             if (p.nt & 2) g256_fetch_aux<true, G256P_AUX_EARLY, 16>(p, tide, m0, n0, auxr);
@@ -370,10 +382,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(GemmNtParams p) {
                 atomic_addf(p.colsum + n0 + tide, s);
             }
         }
+#if defined(TIC_MEASURE) && !defined(TIC_SIM)
+        if (p.stamps && TIC_TID == 0) {
+            p.stamps[(size_t)t * 8 + 6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+            p.stamps[(size_t)t * 8 + 7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+        }
+#endif
+        G256P_STAMP(4);
         if (!has_next) break;
         if (HAS_AUX) consume_bias();
         issue(tic_ic<1>{}, tic_ic<2>{}, 1, voa0n, vob0n);   // B1(1)
         wait_vmcnt<8 + N2>();   // B0(0), A0(0), B1(0) of the next tile have landed (header: the N2 stores of rows 128..255 are younger)
+        G256P_STAMP(5);   // (index t: the tile that just ended) -> stamp 0 of the next tile follows immediately
         t = t_next;
         m0 = m0n;
         n0 = n0n;
