@@ -37,7 +37,10 @@ const char* tic_last_error_string(void);
  *   "gemm_tile"  0 (auto) | 128 | 256       which NT / TN tile family to use
  *   "tn_streamk" 1 (256 shares) | 0 | n     stream-K split of the grouped dW launch
  *   "tn_phase"   1 | 0                      phase-aligned vs flat stream-K split
- *   "tn_mfma"    16 | 32                    MFMA shape of the grouped dW stream-K launch (16x16x32 default, 32x32x16)
+ *   "tn_mfma"    0 (auto) | 16 | 32         MFMA shape of the grouped dW stream-K launch (16x16x32 for long reductions, else 32x32x16)
+ *   "tn_block"   -1 (auto) | 0 | n          tile-walk block width of that launch (XCD-sized blocks | row-major | fixed)
+ *   "gemm_persist" 0 | 1                    persistent form of the 256x256 NT kernel (measured slower: off)
+ *   "gemm_pgrid" 256                        its grid (tests)
  *   "stream_nt"  bit mask, default 13       non-temporal cache policy: 1 LayerNorm, 2 AdamW, 4 GEMM epilogue stores, 8 epilogue operand loads
  *   "attn_fwd_waves" 8 | 4                   waves per (image, head) workgroup of the attention forward
  *   "gemm_stagger" -1 (auto) | 0 | n        s_sleep rounds by which every other first-wave workgroup of the 256x256 NT kernel starts late

@@ -489,4 +489,4 @@ def check_persistent_nt_matches(env, M, N, K, pgrid):
     finally:
         env._call("tic_set_option", b"gemm_tile", 0)
         env._call("tic_set_option", b"gemm_pgrid", 256)
-        env._call("tic_set_option", b"gemm_persist", 1)
+        env._call("tic_set_option", b"gemm_persist", 0)

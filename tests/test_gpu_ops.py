@@ -93,7 +93,7 @@ def test_gemm_tn_group(env, M, shapes):
     finally:
         call("tic_set_option", b"gemm_tile", 0)
         call("tic_set_option", b"tn_streamk", 1)
-        call("tic_set_option", b"tn_mfma", 16)
+        call("tic_set_option", b"tn_mfma", 0)
 
 
 @pytest.mark.parametrize("S,H,W", [(32, 40, 48), (224, 256, 256)])

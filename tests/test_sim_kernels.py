@@ -110,7 +110,7 @@ def test_gemm_tn_group_phase_aligned_split(env, mfma):
     finally:
         call("tic_set_option", b"gemm_tile", 0)
         call("tic_set_option", b"tn_streamk", 1)
-        call("tic_set_option", b"tn_mfma", 16)
+        call("tic_set_option", b"tn_mfma", 0)
 
 
 @pytest.mark.parametrize("M,N,K,pgrid", [(600, 512, 192, 2), (300, 256, 128, 1)])

@@ -94,7 +94,7 @@ def test_stock_optimizer_after_relink_refreshes_operand_copies():
     x = torch.randn(2, 3, 32, 32)
     y = torch.tensor([1, 2])
     m(x)                                   # operand copies built for the current weights
-    e.params = e.params.clone()            # what `.to(device)` does: a NEW flat buffer ...
+    e.replace_params(e.params.clone())     # what `.to(device)` does: a NEW flat buffer ...
     m._relink()                            # ... and every Parameter re-pointed at it (p.data = view)
     opt = torch.optim.SGD(m.parameters(), lr=0.5)
     for _ in range(2):

@@ -71,13 +71,17 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
     return TIC_OK;
 }
 #endif
-static int g_opt_gemm_persist = 1;      // persistent 256x256 NT kernel (gemm256p.h) where a launch has more tiles than workgroups; 0: never
+static int g_opt_gemm_persist = 0;      // 1: persistent 256x256 NT kernel (gemm256p.h) where a launch has more tiles than workgroups.  OFF by default:
+                                        // bit-identical, but 1.9 % SLOWER on the step (tools/ab_step.py gemm_persist 0 1: 130.3 vs 132.8 ms) -- what it
+                                        // removes (2.0 us prologue + 1.6 us between workgroups per tile) was the cover of the previous tile's store
+                                        // drain, which now runs into the next K loop instead (profiles/r02_tile_timeline_persistent.log)
 static int g_opt_gemm_pgrid = 256;      // its grid: one workgroup per CU (tests shrink it to force several tiles per workgroup)
 static int g_opt_gemm_stagger_mask = 0x7f;   // bit e: apply "gemm_stagger" to epilogue e
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
 static int g_opt_tn_block = -1;   // tile-walk block width of the grouped dW launch: -1 auto (one XCD share per block), 0 row-major, n fixed
-static int g_opt_tn_mfma = 16;    // grouped dW stream-K launch on v_mfma_f32_16x16x32_bf16 (default) or 32x32x16 (A/B)
+static int g_opt_tn_mfma = 0;     // MFMA shape of the grouped dW stream-K launch: 0 auto (16x16x32 from 512 M steps per tile on: -1.7 % at M = 65 404,
+                                  // but +2..5 % at M = 12 608, tools/dw_ab.py tn_mfma 16 32), 16, 32
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 extern "C" int tic_set_option(const char* name, int value) {
     if (name && !strcmp(name, "ln_blocks") && value >= 64 && value <= 65536) {
@@ -130,7 +134,7 @@ extern "C" int tic_set_option(const char* name, int value) {
         g_opt_tn_block = value;
         return TIC_OK;
     }
-    if (name && !strcmp(name, "tn_mfma") && (value == 16 || value == 32)) {
+    if (name && !strcmp(name, "tn_mfma") && (value == 0 || value == 16 || value == 32)) {
         g_opt_tn_mfma = value;
         return TIC_OK;
     }
@@ -376,7 +380,7 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
                 return tic_after_launch("gemm_tn(stream-K)");
             }
             TIC_RT_TIMER_MARK(0, stream);
-            if (g_opt_tn_mfma == 32) {
+            if (g_opt_tn_mfma == 32 || (g_opt_tn_mfma == 0 && nsteps < 512)) {
                 TIC_RT_MAX_LDS(gemm_tn256_streamk_mfma32_kernel, G256_LDS_BYTES);
                 TIC_LAUNCH(gemm_tn256_streamk_mfma32_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
             } else {

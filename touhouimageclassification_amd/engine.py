@@ -127,13 +127,20 @@ class VitEngine:
         device = torch.device(device)
         if device == self.params.device:
             return
-        self.params = self.params.to(device)
-        self.grads = None if self.grads is None else self.grads.to(device)
+        self.replace_params(self.params.to(device))
+
+    def replace_params(self, flat: torch.Tensor) -> None:
+        """adopt a NEW flat master-weight buffer (what `.to(device)` does): everything that holds a pointer into the old one --
+        the per-batch-size state records with their workspaces, the bf16 operand copies, the gradient buffer -- is dropped or moved"""
+        if flat.dtype != torch.float32 or flat.numel() != self.lay.n_params:
+            raise ValueError("replace_params: need the flat fp32 buffer of this layout")
+        self.params = flat
+        self.grads = None if self.grads is None else self.grads.to(flat.device)
         self.w16 = self.wT16 = None
         self._ws.clear()
         self._slot_gen.clear()
         self._weights_version = -1
-        self.device = device
+        self.device = flat.device
 
     def _ensure_device_state(self) -> None:
         dev = self.params.device
