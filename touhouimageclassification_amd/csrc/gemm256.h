@@ -188,42 +188,41 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int tid, int m0, int n0, u3
 }
 
 // 4 columns per thread: the fp32-output epilogues (RESID, PATCH).  c8 = tid & 63, rows (tid >> 6) + 8 k.
-template <int EPI, bool NTS, bool NTL>
-TIC_DEV void g256_finish_f32(const GemmNtParams& p, int tid, int m0, int n0) {
-    constexpr int PF = 4;
+// The extra operand (the fp32 residual tile, 256 KiB per workgroup; the position rows for PATCH) is requested like the bf16
+// operand tile above: G256_EX_EARLY of a thread's 32 rows before the staging pass, the rest right after it -- the whole tile is
+// in flight when the second pass starts.  Fetched 4 rows deep inside the pass (round 1) the pass ran at the latency-bound rate
+// of 32 KiB in flight per CU: 18.2 us for 512 KiB (tools/tile_timeline.py --in-step).
+#define G256_EX_EARLY 16
+template <int EPI, bool NTL, int K0, int K1>
+TIC_DEV void g256_fetch_ex(const GemmNtParams& p, int tid, int m0, int n0, f32x4 (&ex)[32]) {
     const int c8 = tid & 63, rsub = tid >> 6;
     const int n = n0 + c8 * 4;
-    f32x4 ex[2][PF];
-    auto src_of = [&](int m) -> const float* {
-        if (EPI == TIC_EPI_RESID) return p.resid + (size_t)m * p.N + n;
-        return p.rowtab + (size_t)(1 + m % p.patches) * p.N + n;
-    };
-    auto fetch = [&](int b) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int m = m0 + (b * PF + i) * 8 + rsub;
-            ex[b & 1][i] = (m < p.M) ? ld_f4<NTL && EPI == TIC_EPI_RESID>(src_of(m)) : f32x4{0.f, 0.f, 0.f, 0.f};   // the position table is re-read: never NT
+    for (int k = K0; k < K1; ++k) {
+        const int m = m0 + k * 8 + rsub;
+        const float* src = (EPI == TIC_EPI_RESID) ? p.resid + (size_t)m * p.N + n : p.rowtab + (size_t)(1 + m % p.patches) * p.N + n;
+        ex[k] = (m < p.M) ? ld_f4<NTL && EPI == TIC_EPI_RESID>(src) : f32x4{0.f, 0.f, 0.f, 0.f};   // the position table is re-read: never NT
+    }
+}
+
+template <int EPI, bool NTS, bool NTL>
+TIC_DEV void g256_finish_f32(const GemmNtParams& p, int tid, int m0, int n0, f32x4 (&ex)[32]) {
+    const int c8 = tid & 63, rsub = tid >> 6;
+    const int n = n0 + c8 * 4;
+    g256_fetch_ex<EPI, NTL, G256_EX_EARLY, 32>(p, tid, m0, n0, ex);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        const int row = k * 8 + rsub, m = m0 + row;
+        const u32x2 u = __builtin_bit_cast(u32x2, lds_ld64(g256_stage_off(row, c8)));
+        if (m >= p.M) continue;
+        const f32x4 e = ex[k];
+        const f32x4 y = f32x4{bf_lo(u[0]) + e[0], bf_hi(u[0]) + e[1], bf_lo(u[1]) + e[2], bf_hi(u[1]) + e[3]};
+        size_t orow = (size_t)m;
+        if (EPI == TIC_EPI_PATCH) {
+            const int img = m / p.patches;
+            orow = (size_t)img * (p.patches + 1) + 1 + (m - img * p.patches);
         }
-    };
-    fetch(0);
-#pragma unroll
-    for (int b = 0; b < 32 / PF; ++b) {
-        if (b + 1 < 32 / PF) fetch(b + 1);
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int k = b * PF + i;
-            const int row = k * 8 + rsub, m = m0 + row;
-            const u32x2 u = __builtin_bit_cast(u32x2, lds_ld64(g256_stage_off(row, c8)));
-            if (m >= p.M) continue;
-            const f32x4 e = ex[b & 1][i];
-            const f32x4 y = f32x4{bf_lo(u[0]) + e[0], bf_hi(u[0]) + e[1], bf_lo(u[1]) + e[2], bf_hi(u[1]) + e[3]};
-            size_t orow = (size_t)m;
-            if (EPI == TIC_EPI_PATCH) {
-                const int img = m / p.patches;
-                orow = (size_t)img * (p.patches + 1) + 1 + (m - img * p.patches);
-            }
-            st_f4<NTS>(p.out_f32 + orow * p.N + n, y);
-        }
+        st_f4<NTS>(p.out_f32 + orow * p.N + n, y);
     }
 }
 
@@ -437,6 +436,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         else g256_fetch_aux<false, 0, G256_AUX_EARLY>(p, tide, m0, n0, auxr);
         sched_fence();
     }
+    f32x4 exr[32];
+    if (EPI == TIC_EPI_RESID || EPI == TIC_EPI_PATCH) {
+        if (p.nt & 2) g256_fetch_ex<EPI, true, 0, G256_EX_EARLY>(p, tide, m0, n0, exr);
+        else g256_fetch_ex<EPI, false, 0, G256_EX_EARLY>(p, tide, m0, n0, exr);
+        sched_fence();
+    }
     if (wr == 0 && !(DBG & 16)) g256_barrier();   // re-balance the stagger
     g256_barrier();                // every wave's LDS reads and DMA writes have retired: the tile buffers are free
 
@@ -463,7 +468,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         else FN<EPI, true, true>(p, tide, m0, n0, ##__VA_ARGS__);               \
     } while (0)
     if (EPI == TIC_EPI_RESID || EPI == TIC_EPI_PATCH)
-        G256_FINISH(g256_finish_f32);
+        G256_FINISH(g256_finish_f32, exr);
     else
         G256_FINISH(g256_finish_bf16, auxr);
 #undef G256_FINISH
