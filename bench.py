@@ -179,6 +179,7 @@ def main():
     ap.add_argument("--sweep", default="32,64,128", help="per-GPU batch sizes reported beside the headline")
     ap.add_argument("--autograd", action="store_true", help="drive the step through torch autograd + F.cross_entropy (plugin surface) instead of the fused step")
     ap.add_argument("--aug", action="store_true", help="BASELINE config 3: include the on-GPU augmentation (uint8 256x256 thumbnails -> crop/flip/jitter/gray/erase/normalise) and MixUp/CutMix (soft labels) in every timed step")
+    ap.add_argument("--bf16-buckets", action="store_true", help="N > 1: gradient buckets cross the links as bf16 (BucketedGradSync(compress='bf16')); default fp32")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="launch rehearsal on a 1-GPU box: all N ranks share device 0 and the collectives go over gloo (RCCL refuses a "
                          "duplicate device). Exercises the self-launch and the DP code path; the number it prints is not a result")
@@ -224,7 +225,7 @@ def main():
     model.reset_parameters(seed=0)
     init_params = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None   # CPU copy for the oracle
     model.to(dev)
-    sync = BucketedGradSync(model)
+    sync = BucketedGradSync(model, compress="bf16" if args.bf16_buckets else None)
     sync.broadcast_parameters()
     opt = FusedAdamW(model, lr=1e-5, weight_decay=0.01)   # ntrain.py:256-257
     g = torch.Generator().manual_seed(1234 + rank)
@@ -312,7 +313,7 @@ def main():
         dp = dict(collective="gloo (one-GPU rehearsal)" if args.rehearse_one_gpu else "RCCL all_reduce(SUM) per bucket, side stream",
                   ranks_observed=rccl_ranks, ms_per_step_slowest_rank=round(1e3 * slowest / args.steps, 3),
                   ms_per_step_fastest_rank=round(1e3 * fastest / args.steps, 3), ms_per_step_no_allreduce=round(ms_off, 3),
-                  allreduce_exposed_ms=round(ms_on - ms_off, 3), grad_bytes_per_step=4 * model._engine.lay.n_params,
+                  allreduce_exposed_ms=round(ms_on - ms_off, 3), grad_bytes_per_step=(2 if args.bf16_buckets else 4) * model._engine.lay.n_params,
                   buckets=len(model._engine.buckets()))
 
     # ---- realistic per-GPU batches (outside the headline timed region) --------------------------------------------------------

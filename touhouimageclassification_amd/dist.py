@@ -16,8 +16,16 @@ import torch.distributed as dist
 
 
 class BucketedGradSync:
-    def __init__(self, model, process_group=None, force: bool = False):
-        """force=True keeps the per-bucket collectives even at world size 1 (exercises the stream / event path on one GPU)."""
+    def __init__(self, model, process_group=None, force: bool = False, compress: Optional[str] = None):
+        """force=True keeps the per-bucket collectives even at world size 1 (exercises the stream / event path on one GPU).
+        compress="bf16": every bucket crosses the links as bf16 (half the bytes: 0.6 instead of 1.2 GB per ViT-L step) -- rounded
+        once before the SUM, accumulated by the collective in bf16, widened back into the fp32 gradient buffer afterwards.  An
+        option for small per-GPU batches, where the fp32 exchange is a visible share of the step (~14 ms on a single
+        ring against a 26 ms step at B = 64); the default keeps the gradients fp32 end to end."""
+        if compress not in (None, "bf16"):
+            raise ValueError("compress must be None or 'bf16'")
+        self.compress = compress
+        self._wire = None   # bf16 staging buffer, one flat tensor the size of the largest bucket
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -32,15 +40,28 @@ class BucketedGradSync:
         """multiply the loss gradient by this so that SUM over ranks == mean over the global batch"""
         return 1.0 / self.world
 
+    def _reduce(self, grad_slice: torch.Tensor) -> None:
+        if self.compress is None:
+            dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        if self._wire is None or self._wire.numel() < grad_slice.numel() or self._wire.device != grad_slice.device:
+            self._wire = torch.empty(max(b - a for _, a, b in self.model._engine.buckets()), dtype=torch.bfloat16, device=grad_slice.device)
+        wire = self._wire[:grad_slice.numel()]
+        wire.copy_(grad_slice)
+        dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg)
+        grad_slice.copy_(wire)
+
     def _on_bucket(self, name: str, grad_slice: torch.Tensor) -> None:
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.pg)
-        else:   # gloo on CPU (tests)
+                self._reduce(grad_slice)   # (side-stream order keeps the shared bf16 staging buffer safe between buckets)
+        elif self.compress is None:   # gloo on CPU (tests)
             self._works.append(dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self._reduce(grad_slice)
 
     def wait(self) -> None:
         """call before optimizer.step(): the compute stream waits for every bucket's all-reduce"""
