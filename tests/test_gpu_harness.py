@@ -415,3 +415,42 @@ def test_expert_parallel_two_ranks_match_dense_on_gpu(tmp_path):
         assert (got["expert_grad"] - ref).norm() <= 0.03 * ref.norm() + 1e-6
         refg = dense.gate.vit.classifier.weight.grad.cpu() / E
         assert (got["gate_grad"] - refg).norm() <= 0.05 * refg.norm() + 1e-6
+
+
+# ---- a15: the augmentation presets on the GPU, as distributions ----------------------------------------------------------------
+def test_augmentation_presets_on_gpu_have_torchvision_statistics():
+    """`GpuAugment` end to end (batched parameter sampling on the host + `tic_augment` on the GPU) on 1024 copies of one asymmetric
+    colour pattern: RandomGrayscale p = 0.2 (grey-only preset, ntrain.py:97-102); RandomHorizontalFlip p = 0.5 and RandomErasing
+    p = 0.5 with an area in (0.02, 0.33) of the image (generalization preset, ntrain.py:122-128); no augmentation = resize +
+    normalise (ntrain.py:132-136).  Parity of the pixels themselves: tests/golden/aug_cases.npz."""
+    from touhouimageclassification_amd.aug import GpuAugment, IMAGENET_MEAN, IMAGENET_STD
+    B, S = 1024, 64
+    img = torch.zeros(96, 96, 3, dtype=torch.uint8)
+    img[:, :48, 0] = 220      # left half red, right half blue: a flip swaps them
+    img[:, 48:, 2] = 220
+    img[:, :, 1] = 60
+    raw = img.unsqueeze(0).repeat(B, 1, 1, 1).to(DEV)
+    mean = torch.tensor(IMAGENET_MEAN, device=DEV).view(1, 3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=DEV).view(1, 3, 1, 1)
+    # grayscale
+    px = GpuAugment("grey", S, seed=1)(raw) * std + mean
+    gray = ((px[:, 0] - px[:, 1]).abs().amax((1, 2)) < 2e-3) & ((px[:, 1] - px[:, 2]).abs().amax((1, 2)) < 2e-3)
+    assert 0.15 < gray.float().mean().item() < 0.25, gray.float().mean().item()
+    # erasing + flip (random resized crop on: only crops that straddle the colour boundary tell left from right)
+    norm = GpuAugment("generalization", S, seed=2)(raw)
+    erased = norm.abs().sum(1) < 1e-6                      # RandomErasing writes 0 into the NORMALISED image
+    frac = erased.float().mean((1, 2))
+    has = frac > 0
+    assert 0.44 < has.float().mean().item() < 0.56, has.float().mean().item()
+    assert frac[has].min().item() > 0.012 and frac[has].max().item() < 0.36
+    px = norm * std + mean
+    w = (~erased).float()
+    red_l = (px[:, 0, :, : S // 2] * w[:, :, : S // 2]).sum((1, 2)) / w[:, :, : S // 2].sum((1, 2)).clamp_min(1)
+    red_r = (px[:, 0, :, S // 2:] * w[:, :, S // 2:]).sum((1, 2)) / w[:, :, S // 2:].sum((1, 2)).clamp_min(1)
+    decided = (red_l - red_r).abs() > 0.2
+    assert decided.float().mean().item() > 0.5
+    flipped = (red_r > red_l)[decided]
+    assert 0.43 < flipped.float().mean().item() < 0.57, flipped.float().mean().item()
+    # no augmentation: the pattern comes through resized and normalised
+    plain = GpuAugment("none", S)(raw[:4]) * std + mean
+    assert (plain[:, 0, :, : S // 2 - 2] > 0.8).all() and (plain[:, 2, :, S // 2 + 2:] > 0.8).all() and (plain[:, 1] - 60 / 255).abs().max() < 2e-2
