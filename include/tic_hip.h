@@ -39,6 +39,7 @@ const char* tic_last_error_string(void);
  *   "tn_phase"   1 | 0                      phase-aligned vs flat stream-K split
  *   "tn_mfma"    0 (auto) | 16 | 32         MFMA shape of the grouped dW stream-K launch (16x16x32 for long reductions, else 32x32x16)
  *   "tn_block"   -1 (auto) | 0 | n          tile-walk block width of that launch (XCD-sized blocks | row-major | fixed)
+ *   "gemm_split" -1 (auto) | 0 | 2 | 4       split-K form of the 256x256 NT kernel (needs tic_gemm_nt_scratch)
  *   "gemm_persist" 0 | 1                    persistent form of the 256x256 NT kernel (measured slower: off)
  *   "gemm_pgrid" 256                        its grid (tests)
  *   "stream_nt"  bit mask, default 13       non-temporal cache policy: 1 LayerNorm, 2 AdamW, 4 GEMM epilogue stores, 8 epilogue operand loads
@@ -55,6 +56,13 @@ int tic_set_option(const char* name, int value);
 int tic_probe_stream(const float* src, float* dst, float* sink, long n, int blocks, int mode, tic_stream_t stream);
 int tic_kernel_timer_enable(int on);
 int tic_kernel_timer_read(int* launches, float* total_ms);
+
+/* Scratch for the split-K form of the 256x256 NT kernel (launches with few output tiles and a long reduction: small batches):
+ * caller-owned, at least TIC_NT_SCRATCH_BYTES, 16-byte aligned; its last 4 KiB are flag words the caller zeroes ONCE.  Registered per
+ * host thread and used by every tic_gemm_nt_* / tic_vit_* call of that thread until replaced (NULL: never split); calls that share a
+ * scratch must be on ONE stream.  tic_vit_* use the scratch inside their workspace (TicVitLayout.nt_scratch) by themselves. */
+#define TIC_NT_SCRATCH_BYTES ((size_t)192 * 32 * 512 * 16 + 4096)
+int tic_gemm_nt_scratch(void* scratch, size_t bytes);
 
 /* GEMM epilogues (fused into the MFMA kernel's store) */
 #define TIC_EPI_BF16 0  /* out = bf16(acc + bias)                                   Linear            */
@@ -223,6 +231,7 @@ typedef struct {
     size_t P, hs, hs_stride, layer_ws, layer_ws_stride;
     size_t a1, mean1, rstd1, qkv, lse, o, hmid, a2, mean2, rstd2, u, g; /* inside a layer_ws block; u holds gelu'(fc1 out) */
     size_t zf, meanf, rstdf, logits, dlogits, dzf, dh, dhb, dhb2, du, da, dqkv, dpatch;
+    size_t nt_scratch;                         /* TIC_NT_SCRATCH_BYTES; the caller zeroes its last 4 KiB when it allocates the workspace */
     size_t ws_bytes;
 } TicVitLayout;
 

@@ -490,3 +490,44 @@ def check_persistent_nt_matches(env, M, N, K, pgrid):
         env._call("tic_set_option", b"gemm_tile", 0)
         env._call("tic_set_option", b"gemm_pgrid", 256)
         env._call("tic_set_option", b"gemm_persist", 0)
+
+
+def check_splitk_nt(env, M, N, K, split):
+    """the split-K form of the 256x256 NT kernel (2 or 4 workgroups per tile, fp32 partial accumulators handed over through a
+    caller-owned scratch, flags that count launches) against the unsplit kernel and fp32 math: same single rounding to bf16, only the
+    fp32 summation order differs"""
+    from touhouimageclassification_amd import _capi
+    rnd, call, dev = env.rnd, env.call, env.dev
+    A, B, bias = bf(rnd(M, K, scale=0.3)), bf(rnd(N, K, scale=0.3)), rnd(N, scale=0.1)
+    resid = rnd(M, N)
+    scratch = torch.zeros(_capi.NT_SCRATCH_BYTES, dtype=torch.uint8, device=dev)   # flags (last 4 KiB) zeroed once
+
+    def run(epi, sp):
+        env._call("tic_set_option", b"gemm_split", sp)
+        o1 = torch.full((M, N), 3.0, device=dev).to(torch.bfloat16)
+        of = torch.full((M, N), 7.0, device=dev)
+        cs = torch.zeros(N, device=dev)
+        call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), M, N, K, epi, ptr(bias), ptr(o1) if epi == 0 else None, None, ptr(of) if epi == 2 else None,
+             ptr(resid) if epi == 2 else None, None, None, 0, ptr(cs) if epi == 0 else None, None)
+        return (o1 if epi == 0 else of), cs
+
+    env._call("tic_set_option", b"gemm_tile", 256)
+    env._call("tic_gemm_nt_scratch", ptr(scratch), scratch.numel())
+    try:
+        ref32 = A.float() @ B.float().t() + bias
+        for epi in (0, 2):
+            base, bcs = run(epi, 0)
+            for rep in range(3):   # repeated launches: the flags count launches, nothing is cleared in between
+                got, gcs = run(epi, split)
+                if epi == 0:
+                    d = (got.float() - base.float()).abs()
+                    assert float((d > 0).float().mean()) < 0.02 and float(d.max()) <= 0.0625 * max(1.0, float(base.float().abs().max()) / 8), (epi, rep)
+                    torch.testing.assert_close(got.float(), ref32, atol=0.06, rtol=0.02)
+                    torch.testing.assert_close(gcs, bcs, atol=2e-2 * max(1.0, float(bcs.abs().max()) / 10), rtol=1e-3)
+                else:
+                    torch.testing.assert_close(got, resid + bfr(ref32), atol=0.06, rtol=0.02)
+                    assert float(((got - base).abs() > 0).float().mean()) < 0.02
+    finally:
+        env._call("tic_gemm_nt_scratch", None, 0)
+        env._call("tic_set_option", b"gemm_tile", 0)
+        env._call("tic_set_option", b"gemm_split", -1)

@@ -329,6 +329,12 @@ TIC_DEV int lane_id_fresh() { return lane_id(); }
 TIC_DEV int wave_id() { return sim::st().cur->tid >> 6; }
 TIC_DEV uint32_t uniform(uint32_t v) { return v; }
 TIC_DEV void atomic_addf(float* p, float v) { *p += v; }
+// workgroups run one after the other here (producers have the lower block indices): the hand-off is a plain store / compare
+TIC_DEV void flag_publish(unsigned* flag, unsigned value) { *flag = value; }
+TIC_DEV bool flag_wait(const unsigned* flag, unsigned value) {
+    if (*flag != value) sim::die("flag_wait: the producer workgroup has not run (block order)");
+    return true;
+}
 TIC_DEV float fast_exp2(float x) { return exp2f(x); }
 TIC_DEV float fast_rcp(float x) { return 1.0f / x; }
 TIC_DEV void glds16_nt(tic_rsrc_t r, uint32_t lds_off, uint32_t voff, uint32_t soff) { glds16(r, lds_off, voff, soff); }

@@ -117,3 +117,9 @@ def test_gemm_tn_group_phase_aligned_split(env, mfma):
 def test_persistent_nt_kernel_is_bit_identical(env, M, N, K, pgrid):
     """6 tiles on 2 workgroups (3 each, odd K-tile count -> a zero-fill K tile, ragged last row tile) / 2 tiles on 1 workgroup"""
     kc.check_persistent_nt_matches(env, M, N, K, pgrid)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(300, 256, 512, 2), (200, 512, 1024, 4)])
+def test_splitk_nt_kernel(env, M, N, K, split):
+    """2 tiles x 2 parts (4 K tiles each) / 2 tiles x 4 parts: producers run first in the simulator's block order"""
+    kc.check_splitk_nt(env, M, N, K, split)

@@ -16,6 +16,10 @@ F = C.c_float
 SZ = C.c_size_t
 
 
+NT_SCRATCH_BYTES = 192 * 32 * 512 * 16 + 4096   # TIC_NT_SCRATCH_BYTES
+NT_FLAG_BYTES = 4096
+
+
 class TicVitDims(C.Structure):
     _fields_ = [("B", I), ("D", I), ("H", I), ("F", I), ("L", I), ("C", I),
                 ("img", I), ("patch", I), ("chans", I), ("eps", F)]
@@ -30,7 +34,7 @@ class TicVitLayout(C.Structure):
         "P", "hs", "hs_stride", "layer_ws", "layer_ws_stride",
         "a1", "mean1", "rstd1", "qkv", "lse", "o", "hmid", "a2", "mean2", "rstd2", "u", "g",
         "zf", "meanf", "rstdf", "logits", "dlogits", "dzf", "dh", "dhb", "dhb2", "du", "da", "dqkv", "dpatch",
-        "ws_bytes")]
+        "nt_scratch", "ws_bytes")]
 
 
 class TicVitState(C.Structure):
@@ -44,6 +48,7 @@ SIGNATURES = {
     "tic_probe_stream": ([P, P, P, C.c_long, I, I, P], I),
     "tic_kernel_timer_enable": ([I], I),
     "tic_kernel_timer_read": ([P, P], I),
+    "tic_gemm_nt_scratch": ([P, SZ], I),
     "tic_gemm_nt_bf16": ([P, P, I, I, I, I, P, P, P, P, P, P, P, I, P], I),
     "tic_gemm_nt_bf16_ex": ([P, P, I, I, I, I, P, P, P, P, P, P, P, I, P, P], I),
     "tic_layernorm_bwd_ex": ([P, P, L, P, P, P, P, P, P, P, P, P, I, I, P], I),

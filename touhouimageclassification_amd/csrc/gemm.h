@@ -42,6 +42,12 @@ struct GemmNtParams {
     int nt;                  // 256x256 staged epilogue: bit 0 non-temporal output stores, bit 1 non-temporal operand loads
     int gm;                  // m-tiles per group of the XCD-local tile walk (tile_coords), 0 = 8
     int stagger;             // experiment (tic_set_option "gemm_stagger"): s_sleep rounds for every other first-wave workgroup
+    // split-K form of the 256x256 kernel (few tiles, long K): `split` workgroups share a tile, each reduces 1/split of K; the first
+    // split - 1 hand their fp32 accumulators to the last one through `slab` ([tile][part][32][512] float4) and `flags` ([tile][4])
+    int split;               // 1 (off), 2 or 4
+    float* slab;
+    unsigned* flags;
+    unsigned epoch;          // value a flag takes in THIS launch (the host counts launches: flags never need clearing)
 #ifdef TIC_MEASURE
     unsigned long long* stamps;   // measurement build only: [grid][8] s_memrealtime stamps of the 256x256 kernel's stages, or nullptr
 #endif

@@ -229,13 +229,28 @@ TIC_DEV void g256_finish_f32(const GemmNtParams& p, int tid, int m0, int n0, f32
 // DBG (measurement builds only, EPI_BF16): bit 0 = no LDS-DMA, bit 1 = no fragment ds_reads, bit 2 = no MFMA, bit 3 = vmcnt(12)
 // in the loop (6 half-tiles in flight: a RACE, timing only), bit 4 = ONE barrier per phase and no wave-group stagger (a RACE too) -- isolates which
 // of the three pipes bounds the main loop (tic_set_option("gemm_dbg")); results are garbage by construction.
-template <int EPI, int DBG = 0>
+// SPLITK = 1: the split-K form for launches with FEW tiles and a LONG reduction (ViT-L at the batch sizes the reference fine-tunes
+// at: 32 images = 25 row tiles x 4 column tiles = 100 workgroups for the N = 1024, K = 4096 / 3072 GEMMs, a third of the chip, 86
+// us of K loop each).  p.split (2 or 4) workgroups share a tile; workgroup (part q, tile t) = block q * tiles + t reduces K tiles
+// [q nk / split, (q + 1) nk / split).  Parts 0 .. split - 2 are PRODUCERS: accumulators from zero, written as they stand (each
+// thread its own 32 float4, fully coalesced) into slab[t][q], then flag[t][q] = epoch (tic_prims.h flag_publish).  The last part is
+// the CONSUMER: accumulators from the bias, after its K loop it waits for each flag, adds the slab (same thread, same registers:
+// no layout question) and runs the ordinary epilogue.  All split x tiles <= 256 workgroups are resident at once (one per CU), so
+// the consumer never waits for a workgroup that cannot start; its poll is bounded anyway.  One rounding to bf16, as without the
+// split; only the fp32 summation order differs.
+template <int EPI, int DBG = 0, int SPLITK = 0>
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wr = w >> 2, wc = w & 3;
     const int tiles_m = (p.M + 255) / 256, tiles_n = p.N / 256;
     int tm, tn;
-    tile_coords(TIC_BID_X, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn, p.gm > 0 ? p.gm : 8);
+    int tile_id = TIC_BID_X, part = 0, nparts = 1;
+    if (SPLITK) {
+        nparts = p.split;
+        part = TIC_BID_X / (tiles_m * tiles_n);
+        tile_id = TIC_BID_X - part * (tiles_m * tiles_n);
+    }
+    tile_coords(tile_id, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn, p.gm > 0 ? p.gm : 8);
     const int m0 = tm * 256, n0 = tn * 256;
     G256_STAMP(0);
     G256_STAMP_ID();
@@ -256,13 +271,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     const uint32_t vob0 = (uint32_t)(((size_t)(n0 + 2 * w * 8 + (l >> 3)) * p.K + slot_log * 8) * 2);
     const uint32_t row8 = (uint32_t)p.K * 16u;   // 8 rows in bytes
     // which: 0 = A0, 1 = B0, 2 = B1, 3 = A1.  K tiles >= nk become zero fills (see header).
-    const int nk = p.K / 64;
+    const int nk = SPLITK ? (p.K / 64) / nparts : p.K / 64;   // K tiles of THIS workgroup, starting at kt0
+    const int kt0 = SPLITK ? part * nk : 0;
     auto issue = [&](int buf, int kt, int which) {
         if (DBG & 1) return;
         const bool isA = (which == 0 || which == 3);
         const int h = (which >= 2) ? 1 : 0;
         const bool live = kt < nk;
-        const uint32_t soff = live ? (uint32_t)kt * 128u : 0u;
+        const uint32_t soff = live ? (uint32_t)(kt0 + kt) * 128u : 0u;
         const uint32_t base = (uint32_t)buf * G256_BUF_BYTES + (isA ? 0u : 32768u) + (uint32_t)h * 16384u + (uint32_t)(2 * w) * 1024u;
         const uint32_t v0 = (isA ? voa0 : vob0) + (uint32_t)h * 16u * row8;
         glds16(isA ? ra : rb, base, live ? v0 : 0xFFFFFFF0u, soff);
@@ -290,7 +306,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
         for (int nt = 0; nt < 2; ++nt) {
             const int col = n0 + j * 128 + wc * 32 + nt * 16 + 4 * (l >> 4);
             f32x4 b4 = f32x4{zero_v, zero_v, zero_v, zero_v};
-            if (p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+            if (p.bias && (!SPLITK || part == nparts - 1)) b4 = *reinterpret_cast<const f32x4*>(p.bias + col);   // split-K: the consumer only
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -431,19 +447,53 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     // from here on the thread index is re-derived from the hardware: threadIdx-derived registers need not survive the K loop
     const int le = lane_id_fresh(), tide = w * 64 + le;
     u32x4 auxr[16];
-    if (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX) {
+    if ((EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX) && !SPLITK) {
         if (p.nt & 2) g256_fetch_aux<true, 0, G256_AUX_EARLY>(p, tide, m0, n0, auxr);
         else g256_fetch_aux<false, 0, G256_AUX_EARLY>(p, tide, m0, n0, auxr);
         sched_fence();
     }
     f32x4 exr[32];
-    if (EPI == TIC_EPI_RESID || EPI == TIC_EPI_PATCH) {
+    if ((EPI == TIC_EPI_RESID || EPI == TIC_EPI_PATCH) && !SPLITK) {   // (split-K: after the hand-off below -- the slab loads need the registers)
         if (p.nt & 2) g256_fetch_ex<EPI, true, 0, G256_EX_EARLY>(p, tide, m0, n0, exr);
         else g256_fetch_ex<EPI, false, 0, G256_EX_EARLY>(p, tide, m0, n0, exr);
         sched_fence();
     }
     if (wr == 0 && !(DBG & 16)) g256_barrier();   // re-balance the stagger
     g256_barrier();                // every wave's LDS reads and DMA writes have retired: the tile buffers are free
+
+    if (SPLITK) {   // hand-off of the partial accumulators (header); thread t owns float4 slots t, 512 + t, ... of a slab
+        const size_t slab_f4 = (size_t)32 * 512;
+        if (part < nparts - 1) {
+            f32x4* slab = reinterpret_cast<f32x4*>(p.slab) + ((size_t)tile_id * (nparts - 1) + part) * slab_f4 + tide;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) slab[(size_t)(g * 8 + r) * 512] = acc[r >> 2][g >> 1][r & 3][g & 1];
+            wait_vmcnt0();
+            g256_barrier();
+            if (tide == 0) flag_publish(p.flags + tile_id * 4 + part, p.epoch);
+            return;
+        }
+        for (int q = 0; q < nparts - 1; ++q) {   // block-uniform trip count
+            if (tide == 0) flag_wait(p.flags + tile_id * 4 + q, p.epoch);
+            g256_barrier();
+            const f32x4* slab = reinterpret_cast<const f32x4*>(p.slab) + ((size_t)tile_id * (nparts - 1) + q) * slab_f4 + tide;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // 8 loads in flight at a time: 32 registers beside the 128 accumulators
+                f32x4 v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = slab[(size_t)(g * 8 + r) * 512];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r >> 2][g >> 1][r & 3][g & 1] += v[r];
+                sched_fence();
+            }
+        }
+        if (EPI == TIC_EPI_RESID || EPI == TIC_EPI_PATCH) {
+            if (p.nt & 2) g256_fetch_ex<EPI, true, 0, G256_EX_EARLY>(p, tide, m0, n0, exr);
+            else g256_fetch_ex<EPI, false, 0, G256_EX_EARLY>(p, tide, m0, n0, exr);
+            sched_fence();
+        }
+    }
 
     // ---- stage u = bf16(acc) into LDS: rows r = i*4 + mt, column groups g = j*2 + nt
 #pragma unroll

@@ -71,6 +71,7 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
     return TIC_OK;
 }
 #endif
+static int g_opt_gemm_split = -1;       // split-K form of the 256x256 NT kernel: -1 auto, 0 / 1 never, 2 / 4 forced where legal (tests)
 static int g_opt_gemm_persist = 0;      // 1: persistent 256x256 NT kernel (gemm256p.h) where a launch has more tiles than workgroups.  OFF by default:
                                         // bit-identical, but 1.9 % SLOWER on the step (tools/ab_step.py gemm_persist 0 1: 130.3 vs 132.8 ms) -- what it
                                         // removes (2.0 us prologue + 1.6 us between workgroups per tile) was the cover of the previous tile's store
@@ -102,6 +103,10 @@ extern "C" int tic_set_option(const char* name, int value) {
     }
     if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
         g_opt_nt = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "gemm_split") && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4)) {
+        g_opt_gemm_split = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "gemm_persist") && (value == 0 || value == 1)) {
@@ -164,6 +169,16 @@ extern "C" int tic_kernel_timer_read(int* launches, float* total_ms) {
 extern "C" const char* tic_last_error_string(void) { return g_tic_err; }
 
 // ---- GEMM ------------------------------------------------------------------------------------------
+// Scratch for the split-K form of the big NT kernel: caller-owned, >= TIC_NT_SCRATCH_BYTES, the flag words (its last 4 KiB) zeroed
+// ONCE by the caller; per host thread (one stream at a time).  Without it launches never split.
+#define TIC_NT_SLAB_BYTES ((size_t)192 * 32 * 512 * 16)   /* 192 producer workgroups x 256 KiB */
+static thread_local char* g_nt_scratch = nullptr;
+static unsigned g_nt_epoch = 0;
+extern "C" int tic_gemm_nt_scratch(void* scratch, size_t bytes) {
+    TIC_REQUIRE(!scratch || (bytes >= TIC_NT_SLAB_BYTES + 4096 && TIC_ALIGNED16(scratch)), "gemm_nt_scratch: need %zu bytes, 16-byte aligned", TIC_NT_SLAB_BYTES + 4096);
+    g_nt_scratch = (char*)scratch;
+    return TIC_OK;
+}
 extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
                                    void* out_bf16, void* out2_bf16, float* out_f32, const float* resid,
                                    const void* aux_bf16, const float* rowtab, int patches, float* colsum, tic_stream_t stream);
@@ -212,6 +227,34 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         ++g_dbg_nt_launches;
     }
 #endif
+    // few tiles, long reduction, scratch available: 2 or 4 workgroups per tile (gemm256.h SPLITK).  K tiles per part must be even
+    // (the K loop runs tile pairs) and every workgroup must be resident at once (<= 256, one per CU)
+    int split = 1;
+    if (big && g_nt_scratch && g_opt_gemm_split != 0 && g_opt_gemm_split != 1 && (epilogue == TIC_EPI_BF16 || epilogue == TIC_EPI_RESID)) {
+        const int nk_ = K / 64;
+        for (int sp = 4; sp >= 2; sp >>= 1) {
+            if (g_opt_gemm_split > 0 && sp != g_opt_gemm_split) continue;
+            if (nk_ % (2 * sp) != 0 || grid * sp > 256) continue;
+            // auto: worth it when a part still runs >= 12 K tiles (the hand-off costs about as much as 8-10 of them)
+            if (g_opt_gemm_split < 0 && (nk_ / sp < 12 || grid > 128)) continue;
+            split = sp;
+            break;
+        }
+    }
+    p.split = split;
+    p.slab = (float*)g_nt_scratch;
+    p.flags = (unsigned*)(g_nt_scratch ? g_nt_scratch + TIC_NT_SLAB_BYTES : nullptr);
+    p.epoch = split > 1 ? ++g_nt_epoch : 0;
+    if (split > 1 && p.epoch == 0) p.epoch = ++g_nt_epoch;   // 0 is what freshly zeroed flags hold
+#define TIC_GEMM_NT_LAUNCH_S(E)                                                                      \
+    do {                                                                                             \
+        if (split > 1) {                                                                             \
+            TIC_RT_MAX_LDS((gemm_nt256_kernel<E, 0, 1>), G256_NT_LDS_BYTES);                         \
+            TIC_LAUNCH((gemm_nt256_kernel<E, 0, 1>), grid * split, 512, G256_NT_LDS_BYTES, stream, p); \
+        } else {                                                                                     \
+            TIC_GEMM_NT_LAUNCH_P(E);                                                                 \
+        }                                                                                            \
+    } while (0)
     // more tiles than CUs and an epilogue without second-pass loads: one persistent workgroup per CU walks the tiles
     const bool persist = big && g_opt_gemm_persist && grid > g_opt_gemm_pgrid && ((double)M + 256.0) * N * 2.0 < 4294967296.0;
 #define TIC_GEMM_NT_LAUNCH_P(E)                                                                      \
@@ -251,7 +294,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
                 break;
             }
 #endif
-            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_BF16);
+            TIC_GEMM_NT_LAUNCH_S(TIC_EPI_BF16);
             break;
         case TIC_EPI_GELU:
             TIC_REQUIRE(out_bf16 && out2_bf16, "gemm_nt: EPI_GELU needs out_bf16 and out2_bf16");
@@ -259,6 +302,11 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
             break;
         case TIC_EPI_RESID:
             TIC_REQUIRE(out_f32 && resid, "gemm_nt: EPI_RESID needs out_f32 and resid");
+            if (split > 1) {
+                TIC_RT_MAX_LDS((gemm_nt256_kernel<TIC_EPI_RESID, 0, 1>), G256_NT_LDS_BYTES);
+                TIC_LAUNCH((gemm_nt256_kernel<TIC_EPI_RESID, 0, 1>), grid * split, 512, G256_NT_LDS_BYTES, stream, p);
+                break;
+            }
             TIC_GEMM_NT_LAUNCH(TIC_EPI_RESID);
             break;
         case TIC_EPI_DGELU:
@@ -282,6 +330,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     }
 #undef TIC_GEMM_NT_LAUNCH
 #undef TIC_GEMM_NT_LAUNCH_P
+#undef TIC_GEMM_NT_LAUNCH_S
     return tic_after_launch("gemm_nt");
 }
 
@@ -908,6 +957,7 @@ extern "C" int tic_vit_layout(const TicVitDims* d, TicVitLayout* o) {
     o->da = w; w += pad256(M * D * 2);
     o->dqkv = w; w += pad256(M * 3 * D * 2);
     o->dpatch = w; w += pad256(B * (N - 1) * D * 2);
+    o->nt_scratch = w; w += pad256(TIC_NT_SCRATCH_BYTES);
     o->ws_bytes = w;
     return TIC_OK;
 }
@@ -922,6 +972,13 @@ struct VitCtx {
     bf16_t* WT;
     char* ws;
     float eps;
+    // while a tic_vit_* call runs, its GEMMs may split K through the scratch inside THIS state's workspace; the caller's own
+    // registration (tic_gemm_nt_scratch) is put back when the call returns, on every path
+    char* prev_scratch = nullptr;
+    bool armed = false;
+    ~VitCtx() {
+        if (armed) g_nt_scratch = prev_scratch;
+    }
 };
 static int vit_ctx(const TicVitState* st, VitCtx& c) {
     TIC_REQUIRE(st && st->params && st->grads && st->w16 && st->wT16 && st->workspace, "vit: null state pointer");
@@ -932,6 +989,9 @@ static int vit_ctx(const TicVitState* st, VitCtx& c) {
     c.PK = (long)d.chans * d.patch * d.patch;
     c.P = st->params; c.G = st->grads; c.W16 = (bf16_t*)st->w16; c.WT = (bf16_t*)st->wT16; c.ws = (char*)st->workspace;
     c.eps = d.eps;
+    c.prev_scratch = g_nt_scratch;
+    c.armed = true;
+    g_nt_scratch = c.ws + c.lay.nt_scratch;
     return TIC_OK;
 }
 

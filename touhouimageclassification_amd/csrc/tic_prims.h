@@ -161,6 +161,30 @@ TIC_DEV int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 TIC_DEV uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 TIC_DEV void atomic_addf(float* p, float v) { atomicAdd(p, v); }
+// Cross-workgroup hand-off inside one launch (the 2- / 4-way split-K form of the 256x256 NT kernel), the guide's counter-free
+// flag form (cdna_hip_programming.md Guideline 16): the PRODUCER's waves have drained their plain stores (s_waitcnt vmcnt(0)) and
+// met at a workgroup barrier; ONE lane then releases at agent scope (writes this XCD's dirty L2 lines back), waits for that, and
+// stores the flag.  The CONSUMER polls the flag from ONE lane with relaxed agent-scope loads (bounded: a lost producer must not
+// hang the device), acquires at agent scope (invalidates this CU's L1), waits for the invalidate; the workgroup barrier that
+// follows orders every other wave's plain loads behind it.
+TIC_DEV void flag_publish(unsigned* flag, unsigned value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // always: hipcc can drop the fence's own wait (guide, compiler hazard)
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+TIC_DEV bool flag_wait(const unsigned* flag, unsigned value) {
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 22); ++spin) {   // ~ seconds at most, then give up (garbage output, terminated kernel)
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == value) {
+            ok = true;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return ok;
+}
 TIC_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32; exp2(-inf) = 0
 TIC_DEV float fast_log2(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32
 TIC_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32 (1 ulp), not the 10-instruction IEEE divide

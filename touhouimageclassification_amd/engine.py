@@ -164,6 +164,7 @@ class VitEngine:
             old, _ = self._ws.popitem(last=False)
             self._slot_gen.pop(old, None)   # a backward that still needs it will raise (stale stamp), not read garbage
         ws = torch.empty(lay.ws_bytes, dtype=torch.uint8, device=self.params.device)
+        ws[lay.nt_scratch + _capi.NT_SCRATCH_BYTES - _capi.NT_FLAG_BYTES:lay.nt_scratch + _capi.NT_SCRATCH_BYTES].zero_()   # split-K flag words: zero ONCE
         st = _capi.TicVitState(self._dims(B), self.params.data_ptr(), self.grads.data_ptr(), self.w16.data_ptr(),
                                self.wT16.data_ptr(), ws.data_ptr())
         self._ws[key] = (ws, st, lay)
