@@ -13,7 +13,7 @@ Rank 0 prints ONE JSON line.
                 max |dlogits|, relative loss difference, top-1 / top-5 agreement
   cpu_baseline  the CPU oracle (oracle/vit_oracle.py, a port) timed on this box's host cores, N = 1 only:
                 3 warm-up + 5 timed steps, median; headline config in fp32, `also` = bf16-autocast and BASELINE config 1
-  sweep         per-GPU batch {32, 64, 128} (the sizes the reference fine-tunes at), outside the headline timed region
+  sweep         per-GPU batch {8, 16, 32, 64, 128} (8 / 16: what the reference's ntrain*.py launchers set; 32-128: SURVEY 8d), outside the headline timed region
   dp            N > 1: RCCL rank count actually observed, per-rank ms/step min / max, all-reduce time not hidden by backward
 """
 import argparse
@@ -171,12 +171,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=332,
                     help="images per GPU per step (weak scaling). 332 x 197 tokens = 256 row tiles of 256: with 4 / 12 / 16 column tiles "
-                         "every big GEMM launches a whole multiple of the 256 CUs; the `sweep` list reports 32 / 64 / 128")
+                         "every big GEMM launches a whole multiple of the 256 CUs; the `sweep` list reports 8 ... 128")
     ap.add_argument("--model", default="large", choices=list(MODELS))
     ap.add_argument("--classes", type=int, default=120)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
-    ap.add_argument("--sweep", default="32,64,128", help="per-GPU batch sizes reported beside the headline")
+    ap.add_argument("--sweep", default="8,16,32,64,128", help="per-GPU batch sizes reported beside the headline")
     ap.add_argument("--autograd", action="store_true", help="drive the step through torch autograd + F.cross_entropy (plugin surface) instead of the fused step")
     ap.add_argument("--aug", action="store_true", help="BASELINE config 3: include the on-GPU augmentation (uint8 256x256 thumbnails -> crop/flip/jitter/gray/erase/normalise) and MixUp/CutMix (soft labels) in every timed step")
     ap.add_argument("--bf16-buckets", action="store_true", help="N > 1: gradient buckets cross the links as bf16 (BucketedGradSync(compress='bf16')); default fp32")

@@ -71,6 +71,9 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
     return TIC_OK;
 }
 #endif
+static int g_opt_tn_streamk_min_steps = 128;   // grouped dW: fewest 64-row steps for which the stream-K split is chosen
+static int g_opt_ln_bwd_rows = 2;        // LayerNorm backward: fewest rows per wave (bounds the number of dgamma / dbeta atomic rows)
+static int g_opt_gemm_big_tiles = 128;   // fewest 256x256 tiles for which the 256x256 NT kernel is chosen (gemm_tile = 0)
 static int g_opt_gemm_split = -1;       // split-K form of the 256x256 NT kernel: -1 auto, 0 / 1 never, 2 / 4 forced where legal (tests)
 static int g_opt_gemm_persist = 0;      // 1: persistent 256x256 NT kernel (gemm256p.h) where a launch has more tiles than workgroups.  OFF by default:
                                         // bit-identical, but 1.9 % SLOWER on the step (tools/ab_step.py gemm_persist 0 1: 130.3 vs 132.8 ms) -- what it
@@ -103,6 +106,18 @@ extern "C" int tic_set_option(const char* name, int value) {
     }
     if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
         g_opt_nt = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "tn_streamk_min_steps") && value >= 1 && value <= (1 << 20)) {
+        g_opt_tn_streamk_min_steps = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "ln_bwd_rows") && value >= 1 && value <= 64) {
+        g_opt_ln_bwd_rows = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "gemm_big_tiles") && value >= 1 && value <= 65536) {
+        g_opt_gemm_big_tiles = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "gemm_split") && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4)) {
@@ -206,8 +221,11 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
 
     p.out = (bf16_t*)out_bf16; p.out2 = (bf16_t*)out2_bf16; p.out_f32 = out_f32; p.resid = resid;
     p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches; p.colsum = colsum;
-    // big products go to the deep-pipelined 256x256 kernel (one block per CU), the rest to the 128x128 one
-    const bool big = (N % 256 == 0) && (g_opt_gemm_tile == 256 || (g_opt_gemm_tile == 0 && (long)M * N >= (long)2048 * 1024));
+    // products with at least g_opt_gemm_big_tiles (128 = half the CUs) 256x256 tiles go to the deep-pipelined 256x256 kernel (one
+    // workgroup per CU); below that the K loop's latency, not throughput, sets the time and the 128x128 kernel's four times as many
+    // workgroups win (tools/small_batch_bench.py: 8-32 images per GPU, N = 1024: 16.7 vs 28.3, 46.9 vs 74.1, 23.9 vs 34.8 us)
+    const bool big = (N % 256 == 0) && (g_opt_gemm_tile == 256 ||
+                                        (g_opt_gemm_tile == 0 && (long)((M + 255) / 256) * (N / 256) >= (long)g_opt_gemm_big_tiles));
     const int grid = big ? (int)(((M + 255) / 256) * (N / 256)) : (int)(tiles_m * ((N + 127) / 128));
     // experiment knob (off by default): every other first-wave workgroup starts n x ~4 us late so that the two halves of the
     // chip alternate between epilogue and main loop.  Stand-alone back-to-back launches of fc1+GELU gain 11 %
@@ -384,7 +402,7 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
         if (N[g] % 256 || K[g] % 256) ok256 = false;
         tiles += (N[g] / 256) * (K[g] / 256);
     }
-    if (ok256 && g_opt_gemm_tile != 128 && (force256 || g_opt_gemm_tile == 256 || (tiles >= 96 && M >= 2048))) {
+    if (ok256 && g_opt_gemm_tile != 128 && (force256 || g_opt_gemm_tile == 256 || (tiles >= 96 && M >= 512))) {
         GemmTnGroupParams gp;
         memset(&gp, 0, sizeof(gp));
         // launch order of the problems: those whose tile count is a whole number of XCD shares (tiles / 8 each) first, so that their
@@ -411,7 +429,11 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
         gp.nprob = nprob; gp.M = M; gp.total_tiles = t;
         const int nsteps = (M + 63) / 64;
         const long shares = g_opt_tn_streamk == 1 ? 256 : g_opt_tn_streamk;   // one share per CU by default
-        if (g_opt_tn_streamk && (long)t * nsteps >= shares) {
+        // short reductions (< 128 steps of 64 rows = fewer than ~42 images of ViT-L tokens): one workgroup per full-M tile; the stream-K
+        // split's partial tiles cost more than the idle quarter of the CUs (tools/small_batch_bench.py: 71 vs 100 us at M = 1576,
+        // 166 vs 175 at M = 6304, 331 vs 288 at M = 12608)
+        const bool streamk = g_opt_tn_streamk && (force256 || g_opt_tn_streamk > 1 || nsteps >= g_opt_tn_streamk_min_steps);
+        if (streamk && (long)t * nsteps >= shares) {
             // phase-aligned split when the tiles divide over the 8 XCDs and the tail workgroups get whole tiles
             int s_main = 0, tpx = 0, tail_each = 0;
             if (g_opt_tn_phase && shares % 8 == 0 && t % 8 == 0) {
@@ -499,6 +521,9 @@ extern "C" int tic_layernorm_bwd_ex(const void* dy_bf16, const float* x, long st
     const int nv = (D + 255) / 256;
     int grid = ln_grid(rows);
     if (grid > 512) grid = 512;   // fewer, longer blocks: one dgamma/dbeta atomic row per block
+    // few rows: every block ends with 3 D atomics onto the same 3 D addresses, so at least g_opt_ln_bwd_rows rows per wave
+    const int few = (rows + 4 * g_opt_ln_bwd_rows - 1) / (4 * g_opt_ln_bwd_rows);
+    if (grid > few) grid = few;
     const size_t lds = (size_t)3 * 4 * D * 4;
 #define TIC_LN_BWD(NV)                                                                                                                   \
     do {                                                                                                                                 \
