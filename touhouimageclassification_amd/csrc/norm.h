@@ -32,20 +32,26 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
         }
     }
     const float invD = 1.0f / (float)D;
-    for (int row = TIC_BID_X * 4 + w; row < rows; row += TIC_NBLK_X * 4) {
+    // the loads of the wave's NEXT row are issued before the current row is reduced and stored
+    f32x4 v[NV];
+    auto load_row = [&](int row, f32x4 (&vo)[NV]) {
         const float* xr = x + (long)row * in_stride;
-        f32x4 v[NV];
-        float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + l) * 4;
-            if (c < D) {
-                v[i] = ld_f4<NT>(xr + c);
-                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            } else {
-                v[i] = f32x4{0, 0, 0, 0};
-            }
+            vo[i] = (c < D) ? ld_f4<NT>(xr + c) : f32x4{0, 0, 0, 0};
         }
+    };
+    const int step = TIC_NBLK_X * 4;
+    int row = TIC_BID_X * 4 + w;
+    if (row < rows) load_row(row, v);
+    for (; row < rows; row += step) {
+        f32x4 vn[NV];
+        const bool more = row + step < rows;   // wave-uniform
+        if (more) load_row(row + step, vn);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);   // columns past D hold zeros
         const float mu = wave_sum(s) * invD;
         float q = 0.f;
 #pragma unroll
@@ -74,6 +80,10 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const float* __restrict__ x
             mean_out[row] = mu;
             rstd_out[row] = rs;
         }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = vn[i];
+        }
     }
 }
 
@@ -98,22 +108,48 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
         dc[i] = f32x4{0, 0, 0, 0};
     }
     const float invD = 1.0f / (float)D;
-    for (int row = TIC_BID_X * 4 + w; row < rows; row += TIC_NBLK_X * 4) {
-        const float mu = mean_in[row], rs = rstd_in[row];
+    // the loads of the wave's NEXT row are issued before the current row is reduced and stored: two rows of loads in flight per wave
+    f32x4 xv[NV], dv[NV];
+    u32x2 dr[NV];
+    float mu = 0.f, rs = 0.f;
+    auto load_row = [&](int row, f32x4 (&xo)[NV], u32x2 (&dro)[NV], f32x4 (&dvo)[NV], float& muo, float& rso) {
+        muo = mean_in[row];
+        rso = rstd_in[row];
         const float* xr = x + (long)row * stride;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + l) * 4;
+            if (c < D) {
+                xo[i] = ld_f4<NT>(xr + c);
+                dro[i] = *reinterpret_cast<const u32x2*>(dy + (long)row * D + c);
+                dvo[i] = dres ? ld_f4<NT>(dres + (long)row * stride + c) : f32x4{0, 0, 0, 0};
+            } else {
+                xo[i] = f32x4{0, 0, 0, 0};
+                dro[i] = u32x2{0, 0};
+                dvo[i] = f32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    int row = TIC_BID_X * 4 + w;
+    const int step = TIC_NBLK_X * 4;
+    if (row < rows) load_row(row, xv, dr, dv, mu, rs);
+    for (; row < rows; row += step) {
+        f32x4 xn[NV], dn[NV];
+        u32x2 drn[NV];
+        float mun = 0.f, rsn = 0.f;
+        const bool more = row + step < rows;   // wave-uniform
+        if (more) load_row(row + step, xn, drn, dn, mun, rsn);
         f32x4 xh[NV], g[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + l) * 4;
             if (c < D) {
-                const f32x4 xv = ld_f4<NT>(xr + c);
-                const u32x2 dr = *reinterpret_cast<const u32x2*>(dy + (long)row * D + c);
-                const float d[4] = {bf2f((bf16_t)(dr[0] & 0xffff)), bf2f((bf16_t)(dr[0] >> 16)),
-                                    bf2f((bf16_t)(dr[1] & 0xffff)), bf2f((bf16_t)(dr[1] >> 16))};
+                const float d[4] = {bf2f((bf16_t)(dr[i][0] & 0xffff)), bf2f((bf16_t)(dr[i][0] >> 16)),
+                                    bf2f((bf16_t)(dr[i][1] & 0xffff)), bf2f((bf16_t)(dr[i][1] >> 16))};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    xh[i][r] = (xv[r] - mu) * rs;
+                    xh[i][r] = (xv[i][r] - mu) * rs;
                     g[i][r] = d[r] * gm[i][r];
                     s1 += g[i][r];
                     s2 += g[i][r] * xh[i][r];
@@ -134,11 +170,21 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = rs * (g[i][r] - c1 - xh[i][r] * c2);
                 const long off = (long)row * stride + c;
-                if (dres) o += ld_f4<NT>(dres + off);
+                o += dv[i];
                 st_f4<NT>(dx + off, o);
                 dc[i] += o;
                 if (dxb) st_u2<NT>(dxb + off, u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])});
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                xv[i] = xn[i];
+                dr[i] = drn[i];
+                dv[i] = dn[i];
+            }
+            mu = mun;
+            rs = rsn;
         }
     }
     // block reduction of dgamma / dbeta: waves -> LDS [2][4][D] -> contiguous atomics

@@ -72,6 +72,7 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
 }
 #endif
 static int g_opt_tn_streamk_min_steps = 128;   // grouped dW: fewest 64-row steps for which the stream-K split is chosen
+static int g_opt_ln_bwd_blocks = 512;    // LayerNorm backward: most blocks per launch
 static int g_opt_ln_bwd_rows = 2;        // LayerNorm backward: fewest rows per wave (bounds the number of dgamma / dbeta atomic rows)
 static int g_opt_gemm_big_tiles = 128;   // fewest 256x256 tiles for which the 256x256 NT kernel is chosen (gemm_tile = 0)
 static int g_opt_gemm_split = -1;       // split-K form of the 256x256 NT kernel: -1 auto, 0 / 1 never, 2 / 4 forced where legal (tests)
@@ -110,6 +111,10 @@ extern "C" int tic_set_option(const char* name, int value) {
     }
     if (name && !strcmp(name, "tn_streamk_min_steps") && value >= 1 && value <= (1 << 20)) {
         g_opt_tn_streamk_min_steps = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "ln_bwd_blocks") && value >= 64 && value <= 65536) {
+        g_opt_ln_bwd_blocks = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "ln_bwd_rows") && value >= 1 && value <= 64) {
@@ -520,7 +525,7 @@ extern "C" int tic_layernorm_bwd_ex(const void* dy_bf16, const float* x, long st
     TIC_REQUIRE(rows >= 1 && D >= 4 && D % 4 == 0 && D <= 1024 && stride % 4 == 0, "layernorm_bwd: need D %% 4 == 0, D <= 1024 (D=%d)", D);
     const int nv = (D + 255) / 256;
     int grid = ln_grid(rows);
-    if (grid > 512) grid = 512;   // fewer, longer blocks: one dgamma/dbeta atomic row per block
+    if (grid > g_opt_ln_bwd_blocks) grid = g_opt_ln_bwd_blocks;   // fewer, longer blocks: one dgamma/dbeta atomic row per block
     // few rows: every block ends with 3 D atomics onto the same 3 D addresses, so at least g_opt_ln_bwd_rows rows per wave
     const int few = (rows + 4 * g_opt_ln_bwd_rows - 1) / (4 * g_opt_ln_bwd_rows);
     if (grid > few) grid = few;
