@@ -531,3 +531,18 @@ def check_splitk_nt(env, M, N, K, split):
         env._call("tic_gemm_nt_scratch", None, 0)
         env._call("tic_set_option", b"gemm_tile", 0)
         env._call("tic_set_option", b"gemm_split", -1)
+
+
+def check_refresh_weights(model):
+    """after a forward, the bf16 operand copies are W (flat) and, per layer, W^T of the four Linear weights: exactly bf16(W) transposed
+    (tic_vit_refresh_weights: one grouped cast+transpose launch over all layers)"""
+    eng = model._engine
+    lay = eng.lay
+    D, F, L = eng.D, eng.F, eng.L
+    flat = eng.params.detach()
+    torch.testing.assert_close(eng.w16.float(), flat.to(torch.bfloat16).float(), atol=0, rtol=0)
+    for l in range(L):
+        for off, toff, R, C in ((lay.wqkv, lay.t_wqkv, 3 * D, D), (lay.wo, lay.t_wo, D, D), (lay.w1, lay.t_w1, F, D), (lay.w2, lay.t_w2, D, F)):
+            w = flat[lay.layer0 + l * lay.layer_stride + off:][: R * C].view(R, C)
+            wt = eng.wT16[l * lay.t_layer_stride + toff:][: R * C].view(C, R)
+            assert torch.equal(wt, w.to(torch.bfloat16).t().contiguous()), (l, R, C)

@@ -4,6 +4,7 @@ against (i) the HF-pinned golden fixtures and (ii) the CPU oracle on the same se
 Tolerances: GPU bf16 vs CPU fp32 logits atol 2e-2 + rtol 2e-2, loss rtol 1e-2, top-1/top-5
 identical where the fp32 margin exceeds the logit tolerance, gradient norms rtol 5e-2."""
 import numpy as np
+from tests import kernel_checks as kc
 import pytest
 import torch
 
@@ -63,6 +64,8 @@ def test_tiny_step_matches_golden_and_oracle(golden_dir):
     opt2.zero_grad()
     torch.nn.functional.cross_entropy(m(x.to(dev)).logits, y.to(dev)).backward()
     opt2.step()
+    m(x.to(dev))   # refreshes the bf16 operand copies from the stepped weights
+    kc.check_refresh_weights(m)
     for k, p in m.named_parameters():
         ref = torch.from_numpy(gold[f"after_adamw/{k}"])
         # every element moves by ~lr; direction can flip only where |g| is at the bf16 noise floor

@@ -1,6 +1,7 @@
 """Whole-model check on CPU: the product's Python surface (ViT factory, module tree, engine, phase
 drivers in C) driven through the simulator build, against the oracle and the HF-pinned golden file."""
 import numpy as np
+from tests import kernel_checks as kc
 import pytest
 import torch
 
@@ -71,6 +72,7 @@ def test_tiny_vit_step_matches_golden(golden_dir):
     opt.step()
     logits2 = m(x).logits   # weights refreshed automatically after the optimizer step
     assert not torch.equal(logits2, logits)
+    kc.check_refresh_weights(m)
     for k, p in m.named_parameters():
         assert (p.detach() - before[k]).abs().max() <= 1.2e-5 + 1e-7
 

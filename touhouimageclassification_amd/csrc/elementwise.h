@@ -104,6 +104,42 @@ __global__ void __launch_bounds__(256) cast_transpose_kernel(const float* __rest
     }
 }
 
+// the same for every Linear weight of a transformer stack in ONE launch: blockIdx.y = layer, blockIdx.x = 64x64 tile of the layer's
+// four matrices (tile_end[i]: running tile count).  96 launches of ~6 us -> one.
+struct CastTransposeGroup {
+    long in_off[4], out_off[4];   // element offsets inside a layer (fp32 parameters / bf16 transposes)
+    int R[4], C[4], tile_end[4];
+    long in_stride, out_stride;   // elements between layers
+};
+__global__ void __launch_bounds__(256) cast_transpose_group_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, CastTransposeGroup gp) {
+    int tile = TIC_BID_X, which = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (TIC_BID_X >= gp.tile_end[i]) {
+            which = i + 1;
+            tile = TIC_BID_X - gp.tile_end[i];
+        }
+    const int R = gp.R[which], C = gp.C[which], tc = C / 64;
+    const float* src = in + (long)TIC_BID_Y * gp.in_stride + gp.in_off[which];
+    bf16_t* dst = out + (long)TIC_BID_Y * gp.out_stride + gp.out_off[which];
+    const int r0 = (tile / tc) * 64, c0 = (tile % tc) * 64, t = TIC_TID;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 2 * (i * 16 + (t >> 4)), col = (t & 15) * 4;
+        const f32x4 va = *reinterpret_cast<const f32x4*>(src + (long)(r0 + row) * C + c0 + col);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(src + (long)(r0 + row + 1) * C + c0 + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_stf((uint32_t)((col + j) * CT_STRIDE + row) * 2u, __builtin_bit_cast(float, pack2bf(va[j], vb[j])));
+    }
+    block_sync();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int crow = i * 16 + (t >> 4), rr = (t & 15) * 4;
+        const bf16x4 v = lds_ld64((uint32_t)(crow * CT_STRIDE + rr) * 2u);
+        *reinterpret_cast<bf16x4*>(dst + (long)(c0 + crow) * R + r0 + rr) = v;
+    }
+}
+
 // flat AdamW over n4*4 elements; optional bf16 shadow of the updated parameters
 template <bool NT = false>
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

@@ -1030,6 +1030,20 @@ extern "C" int tic_vit_refresh_weights(const TicVitState* st, int transposes_onl
     TIC_TRY(vit_ctx(st, c));
     const TicVitLayout& y = c.lay;
     if (!transposes_only) TIC_TRY(tic_cast_bf16(c.P, c.W16, y.n_params, s));
+    if (c.D % 64 == 0 && c.F % 64 == 0 && c.L <= 65535) {   // every Linear weight of the stack in one launch
+        CastTransposeGroup gp;
+        const long in_off[4] = {y.wqkv, y.wo, y.w1, y.w2}, out_off[4] = {y.t_wqkv, y.t_wo, y.t_w1, y.t_w2};
+        const long R[4] = {3 * c.D, c.D, c.F, c.D}, C[4] = {c.D, c.D, c.D, c.F};
+        int tiles = 0;
+        for (int i = 0; i < 4; ++i) {
+            gp.in_off[i] = in_off[i]; gp.out_off[i] = out_off[i]; gp.R[i] = (int)R[i]; gp.C[i] = (int)C[i];
+            tiles += (int)((R[i] / 64) * (C[i] / 64));
+            gp.tile_end[i] = tiles;
+        }
+        gp.in_stride = y.layer_stride; gp.out_stride = y.t_layer_stride;
+        TIC_LAUNCH(cast_transpose_group_kernel, dim3(tiles, (unsigned)c.L), 256, 64 * CT_STRIDE * 2, s, c.P + y.layer0, c.WT, gp);
+        return tic_after_launch("vit_refresh_weights");
+    }
     for (long l = 0; l < c.L; ++l) {
         const float* lp = c.P + y.layer0 + l * y.layer_stride;
         bf16_t* lt = c.WT + l * y.t_layer_stride;
