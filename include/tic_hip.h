@@ -76,6 +76,8 @@ int tic_gemm_nt_scratch(void* scratch, size_t bytes);
 #define TIC_EPI_GELU_DG 5 /* u = bf16(acc + bias); out = bf16(gelu'(u)); out2 = bf16(gelu_erf(u))   fc1 + GELU, derivative saved
                              instead of the pre-activation: the erf / exp work is shared and the backward becomes one multiply */
 #define TIC_EPI_MULAUX 6  /* out = bf16(bf16(acc) * aux)                               backward through GELU with aux = gelu'(u) */
+#define TIC_EPI_ADDAUX 7  /* out = bf16(bf16(acc) + aux), aux bf16 [M, N]; out == aux allowed (in place)   ResNet: input gradient of a 1x1
+                           * convolution added to the gradient of the block's identity branch (TIC/ResNet/model.py:113, out += identity) */
 
 /* C[M,N] = A[M,K] . B[N,K]^T with a fused epilogue.  N % 8 == 0, K % 64 == 0, any M >= 1.
  * Replaces nn.Linear forward (HF:202-205,216-218,235-236,246-247,250-252) and, fed with W^T, the dX half
@@ -194,8 +196,9 @@ int tic_im2col_bf16(const void* x, void* col, int B, int H, int W, int Ci, int k
 int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, int accumulate,
                     tic_stream_t stream);
 /* BatchNorm2d over [M, C] bf16 (+ optional residual add, + optional ReLU): y = relu(bn(x) + identity).  train != 0: batch
- * statistics, running stats (unbiased var) and num_batches_tracked updated; else running stats.  scratch2c: 2*C floats.
- * model.py:51-52,60-61,99-113,150-151 */
+ * statistics, running stats (unbiased var) and num_batches_tracked updated; else running stats.  scratch2c: 2*C floats that are
+ * ZERO on entry and left zero on return (the kernels accumulate into them and clear them: one zero-filled buffer per layer,
+ * allocated once, serves every forward and backward call -- no memset per call).  model.py:51-52,60-61,99-113,150-151 */
 int tic_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                       int64_t* num_batches, float* mean, float* rstd, float* scratch2c, const void* identity, void* y, long M, int C,
                       float eps, float momentum, int train, int relu, tic_stream_t stream);
@@ -203,6 +206,10 @@ int tic_batchnorm_fwd(const void* x, const float* gamma, const float* beta, floa
 int tic_batchnorm_bwd(const void* dy, const void* y_or_null, const void* x, const float* mean, const float* rstd, const float* gamma,
                       float* scratch2c, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M, int C,
                       tic_stream_t stream);
+/* backward of y = relu(bn(x)) WITHOUT a residual add (the first one or two BatchNorms of a block): the ReLU mask is recomputed from
+ * x with the forward's own fp32 expression and bf16 rounding, so y is not read in either pass (12 instead of 16 B per element) */
+int tic_batchnorm_bwd_relu(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           float* scratch2c, void* dx, float* dgamma, float* dbeta, long M, int C, tic_stream_t stream);
 int tic_maxpool3x3s2_fwd(const void* x, void* y, int B, int H, int W, int C, tic_stream_t stream);                       /* model.py:152 */
 int tic_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, tic_stream_t stream);
 int tic_avgpool_fwd(const void* x, void* y, int B, int HW, int C, tic_stream_t stream);                                  /* model.py:164,222 */

@@ -65,6 +65,11 @@ def check_gemm_nt_gelu_resid_dgelu_patch(env, N=128, K=128, imgs=3, Pn=50):
     torch.testing.assert_close(d6.float(), bfr(bfr(A.float() @ B.float().t()) * dg5.float()), atol=2e-3, rtol=1.6e-2)   # two bf16 ulps: the reference product rounds too
     torch.testing.assert_close(d6.float(), uu.grad, atol=0.03, rtol=0.03)
     torch.testing.assert_close(cs6, d6.float().sum(0), atol=0.05, rtol=0.02)
+    # ADDAUX (7): the product added onto a bf16 tensor IN PLACE, exactly bf16(bf16(acc) + aux) = what a separate add pass would store
+    acc7 = bf(rnd(M, N))
+    want7 = bfr(bfr(A.float() @ B.float().t()) + acc7.float())
+    call("tic_gemm_nt_bf16", ptr(A), ptr(B), M, N, K, 7, None, ptr(acc7), None, None, None, ptr(acc7), None, 0, None)
+    torch.testing.assert_close(acc7.float(), want7, atol=2e-2, rtol=1.6e-2)   # one bf16 ulp of the PRODUCT (it rounds before the add, which may cancel)
     # patch epilogue: M = images * patches, rows remapped past the CLS slot
     pos = rnd(Pn + 1, N)
     h = torch.zeros(imgs * (Pn + 1), N, device=dev)

@@ -23,6 +23,16 @@ def test_conv_ops_against_torch():
     y = col.float() @ wp.float().t()
     ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), bfr(w), None, stride=s, padding=p).permute(0, 2, 3, 1).reshape(-1, Co)
     torch.testing.assert_close(y, ref, atol=1e-3, rtol=1e-3)
+    # the stem's shape class (Ci = 3, 7x7 / 2, pad 3): 8 consecutive k per thread, K = 147 padded to 192 with zeros
+    Hs, Ws = 13, 12
+    xs = bf(torch.randn(B, Hs, Ws, 3))
+    ws = torch.randn(8, 3, 7, 7) * 0.2
+    Hso, Wso = (Hs + 6 - 7) // 2 + 1, (Ws + 6 - 7) // 2 + 1
+    cols = torch.full((B * Hso * Wso, 192), 7.0).to(torch.bfloat16)
+    call("tic_im2col_bf16", ptr(xs), ptr(cols), B, Hs, Ws, 3, 7, 7, 2, 3, None)
+    unf = torch.nn.functional.unfold(xs.float().permute(0, 3, 1, 2), 7, padding=3, stride=2)           # [B, 3*49, L]
+    unf = unf.view(B, 3, 49, Hso * Wso).permute(0, 3, 2, 1).reshape(B * Hso * Wso, 147)                  # tap-major
+    assert torch.equal(cols[:, :147].float(), unf) and float(cols[:, 147:].abs().max()) == 0.0
     # col2im = adjoint of im2col
     dcol = bf(torch.randn(B * Ho * Wo, Kp))
     dx = torch.empty(B * H * W, Ci, dtype=torch.bfloat16)
@@ -47,7 +57,7 @@ def test_batchnorm_and_pools_against_torch():
     ident = bf(torch.randn(M, C))
     gamma, beta = 1 + 0.1 * torch.randn(C), 0.1 * torch.randn(C)
     rm, rv, nb = torch.zeros(C), torch.ones(C), torch.tensor(0)
-    mean, rstd, scr = torch.empty(C), torch.empty(C), torch.empty(2 * C)
+    mean, rstd, scr = torch.empty(C), torch.empty(C), torch.zeros(2 * C)   # zero on entry, left zero by every call
     y = torch.empty(M, C, dtype=torch.bfloat16)
     call("tic_batchnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nb), ptr(mean), ptr(rstd), ptr(scr), ptr(ident), ptr(y), M, C, 1e-5, 0.1, 1, 1, None)
     xr = x.float().requires_grad_(True)
@@ -68,6 +78,16 @@ def test_batchnorm_and_pools_against_torch():
     torch.testing.assert_close(dskip.float(), ir.grad, atol=0.02, rtol=0.02)
     torch.testing.assert_close(dg, gr.grad, atol=0.05, rtol=0.02)
     torch.testing.assert_close(db, br.grad, atol=0.05, rtol=0.02)
+    assert float(scr.abs().max()) == 0.0
+    # y = relu(bn(x)) without the residual add: the backward recomputes the mask from x and must equal the y-masked form exactly
+    y2 = torch.empty(M, C, dtype=torch.bfloat16)
+    call("tic_batchnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nb), ptr(mean), ptr(rstd), ptr(scr), None, ptr(y2), M, C, 1e-5, 0.1, 1, 1, None)
+    dxa_, dxb_ = torch.empty(M, C, dtype=torch.bfloat16), torch.empty(M, C, dtype=torch.bfloat16)
+    dga, dba, dgb, dbb = torch.zeros(C), torch.zeros(C), torch.zeros(C), torch.zeros(C)
+    call("tic_batchnorm_bwd", ptr(dy), ptr(y2), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(scr), ptr(dxa_), None, 0, ptr(dga), ptr(dba), M, C, None)
+    call("tic_batchnorm_bwd_relu", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(scr), ptr(dxb_), ptr(dgb), ptr(dbb), M, C, None)
+    assert torch.equal(dxa_, dxb_) and torch.equal(dga, dgb) and torch.equal(dba, dbb)
+    assert 0.2 < float((y2 == 0).float().mean()) < 0.8
     # pools
     xp = bf(torch.relu(torch.randn(B, H, W, C)))   # post-ReLU input: many ties at 0 -> first-maximum rule matters
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1

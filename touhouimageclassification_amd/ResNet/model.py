@@ -118,7 +118,12 @@ class TicResNet(nn.Module):
     def _call(self, name, *args):
         self.backend.call(name, *args, self.backend.stream())
 
-    def _gemm_nt(self, A, Bw, M, N, K):
+    def _gemm_nt(self, A, Bw, M, N, K, add_into=None):
+        """A [M,K] . Bw [N,K]^T -> bf16 [M,N]; add_into (bf16 [M,N]): the product is ADDED to it in place by the GEMM epilogue
+        (TIC_EPI_ADDAUX: bf16(bf16(acc) + aux), what a separate add pass over the stored product gives)"""
+        if add_into is not None:
+            self._call("tic_gemm_nt_bf16", A.data_ptr(), Bw.data_ptr(), M, N, K, 7, None, add_into.data_ptr(), None, None, None, add_into.data_ptr(), None, 0)
+            return add_into
         out = torch.empty(M, N, dtype=torch.bfloat16, device=A.device)
         self._call("tic_gemm_nt_bf16", A.data_ptr(), Bw.data_ptr(), M, N, K, 0, None, out.data_ptr(), None, None, None, None, None, 0)
         return out
@@ -162,10 +167,18 @@ class TicResNet(nn.Module):
             self._call("tic_im2col_bf16", x.data_ptr(), col.data_ptr(), B, H, W, conv.cin, conv.k, conv.k, conv.stride, conv.pad)
         return self._gemm_nt(col, self._pack(conv, 0), M, conv.cout, conv.kp), col, Ho, Wo
 
+    @staticmethod
+    def _bn_scratch(bn: _BN, dev):
+        """2C floats, zero between calls (the kernels accumulate into them and clear them again): allocated once per layer"""
+        s = bn.__dict__.get("_scratch")
+        if s is None or s.device != dev:
+            s = bn.__dict__["_scratch"] = torch.zeros(2 * bn.c, device=dev)
+        return s
+
     def _bn_fwd(self, bn: _BN, x, M, identity, relu, train):
         dev = x.device
         mean, rstd = torch.empty(bn.c, device=dev), torch.empty(bn.c, device=dev)
-        scratch = torch.empty(2 * bn.c, device=dev)
+        scratch = self._bn_scratch(bn, dev)
         y = torch.empty_like(x)
         self._call("tic_batchnorm_fwd", x.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                    bn.num_batches_tracked.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(),
@@ -223,20 +236,21 @@ class TicResNet(nn.Module):
             self._call("tic_conv_igemm_fwd", dy.data_ptr(), self._pack(conv, 2).data_ptr(), dx.data_ptr(), B, Ho, Wo, conv.cout, conv.cin,
                        conv.k, conv.k, 1, conv.k - 1 - conv.pad)
             return dx
+        if conv.k == 1 and conv.stride == 1:   # the activation gradient IS the GEMM output; an accumulation target rides in its epilogue
+            return self._gemm_nt(dy, self._pack(conv, 1), M, conv.kp, conv.cout, add_into=dx_accumulate_into)
         dcol = self._gemm_nt(dy, self._pack(conv, 1), M, conv.kp, conv.cout)
-        if conv.k == 1 and conv.stride == 1:
-            if dx_accumulate_into is not None:
-                self._call("tic_add_bf16", dx_accumulate_into.data_ptr(), dcol.data_ptr(), dcol.numel())
-                return dx_accumulate_into
-            return dcol
         dx = dx_accumulate_into if dx_accumulate_into is not None else torch.empty(B * H * W, conv.cin, dtype=torch.bfloat16, device=dy.device)
         self._call("tic_col2im_bf16", dcol.data_ptr(), dx.data_ptr(), B, H, W, conv.cin, conv.k, conv.k, conv.stride, conv.pad,
                    1 if dx_accumulate_into is not None else 0)
         return dx
 
-    def _bn_bwd(self, bn: _BN, dy, y_relu, x, mean, rstd, M, dskip=None, skip_accumulate=False):
+    def _bn_bwd(self, bn: _BN, dy, y_relu, x, mean, rstd, M, dskip=None, skip_accumulate=False, relu_from_x=False):
         dx = torch.empty_like(x)
-        scratch = torch.empty(2 * bn.c, device=x.device)
+        scratch = self._bn_scratch(bn, x.device)
+        if relu_from_x:   # y = relu(bn(x)), no residual add: the mask is recomputed from x, y is not read
+            self._call("tic_batchnorm_bwd_relu", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
+                       scratch.data_ptr(), dx.data_ptr(), self._grad_buf(bn.weight).data_ptr(), self._grad_buf(bn.bias).data_ptr(), M, bn.c)
+            return dx
         self._call("tic_batchnorm_bwd", dy.data_ptr(), None if y_relu is None else y_relu.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                    bn.weight.data_ptr(), scratch.data_ptr(), dx.data_ptr(), None if dskip is None else dskip.data_ptr(), 1 if skip_accumulate else 0,
                    self._grad_buf(bn.weight).data_ptr(), self._grad_buf(bn.bias).data_ptr(), M, bn.c)
@@ -309,19 +323,26 @@ class TicResNet(nn.Module):
                 cv, bn = convs[i]
                 col, c, y, m, r, Hi, Wi = steps[i]
                 last = i == len(convs) - 1
-                d = self._bn_bwd(bn, d, y, c, m, r, c.shape[0], dskip=dident if last else None)
-                d = self._conv_bwd(cv, d, col, B, Hi, Wi, need_dx=True)
+                if last:
+                    d = self._bn_bwd(bn, d, y, c, m, r, c.shape[0], dskip=dident)
+                else:
+                    d = self._bn_bwd(bn, d, None, c, m, r, c.shape[0], relu_from_x=True)
+                # the block's first conv: when it is a 1x1 / stride-1 GEMM and the identity branch has no downsample, its input
+                # gradient is added onto the identity-branch gradient by the GEMM epilogue (no separate add pass)
+                fold = i == 0 and blk.downsample is None and cv.k == 1 and cv.stride == 1
+                d = self._conv_bwd(cv, d, col, B, Hi, Wi, need_dx=True, dx_accumulate_into=dident if fold else None)
+                folded = fold
             if blk.downsample is not None:
                 cold, cd, md, rd = rec["ds"]
                 dd = self._bn_bwd(blk.downsample[1], dident, None, cd, md, rd, cd.shape[0])
                 self._conv_bwd(blk.downsample[0], dd, cold, B, rec["H"], rec["W"], need_dx=True, dx_accumulate_into=d)
-            else:
+            elif not folded:
                 self._call("tic_add_bf16", d.data_ptr(), dident.data_ptr(), d.numel())
             dh = d
         col0, c0, a0, m0, r0, H, W, H1, W1, hpool = tape["stem"]
         da0 = torch.empty_like(a0)
         self._call("tic_maxpool3x3s2_bwd", a0.data_ptr(), hpool.data_ptr(), dh.data_ptr(), da0.data_ptr(), B, H1, W1, 64)
-        dc0 = self._bn_bwd(self.bn1, da0, a0, c0, m0, r0, c0.shape[0])
+        dc0 = self._bn_bwd(self.bn1, da0, None, c0, m0, r0, c0.shape[0], relu_from_x=True)
         self._conv_bwd(self.conv1, dc0, col0, B, H, W, need_dx=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -83,6 +83,7 @@ SIGNATURES = {
     "tic_col2im_bf16": ([P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_batchnorm_fwd": ([P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, I, P], I),
     "tic_batchnorm_bwd": ([P, P, P, P, P, P, P, P, P, I, P, P, L, I, P], I),
+    "tic_batchnorm_bwd_relu": ([P, P, P, P, P, P, P, P, P, P, L, I, P], I),
     "tic_maxpool3x3s2_fwd": ([P, P, I, I, I, I, P], I),
     "tic_maxpool3x3s2_bwd": ([P, P, P, P, I, I, I, I, P], I),
     "tic_avgpool_fwd": ([P, P, I, I, I, P], I),

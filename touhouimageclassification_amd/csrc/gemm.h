@@ -86,7 +86,7 @@ TIC_DEV EpiExtra epi_fetch(const GemmNtParams& p, int m, int n) {
     e.u = u32x2{0u, 0u};
     if (m < p.M && n < p.N) {
         if (EPI == TIC_EPI_RESID) e.f = *reinterpret_cast<const f32x4*>(p.resid + (size_t)m * p.N + n);
-        if (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX) e.u = *reinterpret_cast<const u32x2*>(p.aux + (size_t)m * p.N + n);
+        if (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX || EPI == TIC_EPI_ADDAUX) e.u = *reinterpret_cast<const u32x2*>(p.aux + (size_t)m * p.N + n);
         if (EPI == TIC_EPI_PATCH) e.f = *reinterpret_cast<const f32x4*>(p.rowtab + (size_t)(1 + m % p.patches) * p.N + n);
     }
     return e;
@@ -129,6 +129,11 @@ TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, EpiExtra e
         const float d2 = bfround(v[2]) * bf2f((bf16_t)(e.u[1] & 0xffff)), d3 = bfround(v[3]) * bf2f((bf16_t)(e.u[1] >> 16));
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
         return f32x4{d0, d1, d2, d3};
+    } else if (EPI == TIC_EPI_ADDAUX) {
+        const float d0 = bfround(v[0]) + bf2f((bf16_t)(e.u[0] & 0xffff)), d1 = bfround(v[1]) + bf2f((bf16_t)(e.u[0] >> 16));
+        const float d2 = bfround(v[2]) + bf2f((bf16_t)(e.u[1] & 0xffff)), d3 = bfround(v[3]) + bf2f((bf16_t)(e.u[1] >> 16));
+        *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
+        return f32x4{d0, d1, d2, d3};
     } else if (EPI == TIC_EPI_PATCH) {
         const int img = m / p.patches, pi = m - img * p.patches;
         const size_t orow = (size_t)img * (p.patches + 1) + 1 + pi;
@@ -142,7 +147,7 @@ TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, EpiExtra e
 // NR rows x NG column groups per lane; row_of(r) / col_of(g) give the global coordinates, acc_of(r, g) the value
 template <int EPI, int NR, int NG, class RowF, class ColF, class AccF>
 TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF acc_of) {
-    constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX || EPI == TIC_EPI_PATCH);
+    constexpr bool HAS_EXTRA = (EPI == TIC_EPI_RESID || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX || EPI == TIC_EPI_ADDAUX || EPI == TIC_EPI_PATCH);
     constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
     EpiExtra ex[2][NG];
     f32x4 cs[NG];

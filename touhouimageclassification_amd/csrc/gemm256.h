@@ -114,7 +114,7 @@ TIC_DEV void g256_fetch_aux(const GemmNtParams& p, int tid, int m0, int n0, u32x
 template <int EPI, bool NTS, bool NTL>
 TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int tid, int m0, int n0, u32x4 (&aux)[16]) {
     constexpr bool HAS_COLSUM = (EPI == TIC_EPI_BF16 || EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX);
-    if (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX) g256_fetch_aux<NTL, G256_AUX_EARLY, 16>(p, tid, m0, n0, aux);
+    if (EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX || EPI == TIC_EPI_ADDAUX) g256_fetch_aux<NTL, G256_AUX_EARLY, 16>(p, tid, m0, n0, aux);
     constexpr int PF = 4;
     const int c16 = tid & 31, rsub = tid >> 5;
     const int n = n0 + c16 * 8;
@@ -152,14 +152,15 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int tid, int m0, int n0, u3
                 }
                 st_u4<NTS>(p.out + o, dg);
                 st_u4<NTS>(p.out2 + o, g);
-            } else {   // DGELU / MULAUX
+            } else {   // DGELU / MULAUX / ADDAUX
                 const u32x4 a = aux[k];
                 u32x4 d;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float f0 = (EPI == TIC_EPI_DGELU) ? gelu_erf_grad(bf_lo(a[j])) : bf_lo(a[j]);
                     const float f1 = (EPI == TIC_EPI_DGELU) ? gelu_erf_grad(bf_hi(a[j])) : bf_hi(a[j]);
-                    const float d0 = bf_lo(u[j]) * f0, d1 = bf_hi(u[j]) * f1;
+                    const float d0 = (EPI == TIC_EPI_ADDAUX) ? bf_lo(u[j]) + f0 : bf_lo(u[j]) * f0;
+                    const float d1 = (EPI == TIC_EPI_ADDAUX) ? bf_hi(u[j]) + f1 : bf_hi(u[j]) * f1;
                     d[j] = pack2bf(d0, d1);
                     cs[2 * j] += d0;
                     cs[2 * j + 1] += d1;
@@ -447,7 +448,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
     // from here on the thread index is re-derived from the hardware: threadIdx-derived registers need not survive the K loop
     const int le = lane_id_fresh(), tide = w * 64 + le;
     u32x4 auxr[16];
-    if ((EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX) && !SPLITK) {
+    if ((EPI == TIC_EPI_DGELU || EPI == TIC_EPI_MULAUX || EPI == TIC_EPI_ADDAUX) && !SPLITK) {
         if (p.nt & 2) g256_fetch_aux<true, 0, G256_AUX_EARLY>(p, tide, m0, n0, auxr);
         else g256_fetch_aux<false, 0, G256_AUX_EARLY>(p, tide, m0, n0, auxr);
         sched_fence();

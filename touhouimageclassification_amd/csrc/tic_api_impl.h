@@ -222,7 +222,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     GemmNtParams p;
     memset(&p, 0, sizeof(p));
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K;
-    p.bias = (epilogue == TIC_EPI_DGELU || epilogue == TIC_EPI_MULAUX) ? nullptr : bias;
+    p.bias = (epilogue == TIC_EPI_DGELU || epilogue == TIC_EPI_MULAUX || epilogue == TIC_EPI_ADDAUX) ? nullptr : bias;
 
     p.out = (bf16_t*)out_bf16; p.out2 = (bf16_t*)out2_bf16; p.out_f32 = out_f32; p.resid = resid;
     p.aux = (const bf16_t*)aux_bf16; p.rowtab = rowtab; p.patches = patches; p.colsum = colsum;
@@ -343,6 +343,10 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         case TIC_EPI_MULAUX:
             TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_MULAUX needs out_bf16 and aux_bf16");
             TIC_GEMM_NT_LAUNCH_P(TIC_EPI_MULAUX);
+            break;
+        case TIC_EPI_ADDAUX:
+            TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_ADDAUX needs out_bf16 and aux_bf16");
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_ADDAUX);
             break;
         case TIC_EPI_PATCH:
             TIC_REQUIRE(out_f32 && rowtab && patches > 0 && M % patches == 0, "gemm_nt: EPI_PATCH needs out_f32, rowtab, M %% patches == 0");
@@ -833,7 +837,7 @@ extern "C" int tic_im2col_bf16(const void* x, void* col, int B, int H, int W, in
     ConvGeom g;
     TIC_TRY(conv_geom(g, B, H, W, Ci, kh, kw, stride, pad));
     const long M = (long)B * g.Ho * g.Wo;
-    TIC_LAUNCH(im2col_kernel, ew_grid(Ci % 8 == 0 ? M * (g.Kp / 8) : M * g.Kp), 256, 0, stream, (const bf16_t*)x, (bf16_t*)col, g);
+    TIC_LAUNCH(im2col_kernel, ew_grid(M * (g.Kp / 8)), 256, 0, stream, (const bf16_t*)x, (bf16_t*)col, g);
     return tic_after_launch("im2col");
 }
 extern "C" int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, int accumulate,
@@ -853,8 +857,7 @@ extern "C" int tic_batchnorm_fwd(const void* x, const float* gamma, const float*
                                  float eps, float momentum, int train, int relu, tic_stream_t stream) {
     TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && scratch2c && y, "batchnorm_fwd: null pointer");
     TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_fwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
-    if (train) {
-        TIC_RT_MEMSET(scratch2c, 0, (size_t)2 * C * 4, stream);
+    if (train) {   // scratch2c: zero on entry (caller, once), left zero by bn_finalize_kernel
         TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, scratch2c, M, C);
     }
     TIC_LAUNCH(bn_finalize_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, mean, rstd, running_mean, running_var, (long long*)num_batches, M, C, eps,
@@ -862,25 +865,39 @@ extern "C" int tic_batchnorm_fwd(const void* x, const float* gamma, const float*
     TIC_LAUNCH(bn_apply_kernel, ew_grid(M * (C / 8)), 256, 0, stream, (const bf16_t*)x, mean, rstd, gamma, beta, (const bf16_t*)identity, (bf16_t*)y, M, C, relu);
     return tic_after_launch("batchnorm_fwd");
 }
-__global__ void __launch_bounds__(256) bn_param_grad_kernel(const float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+__global__ void __launch_bounds__(256) bn_param_grad_kernel(float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
     const int c = TIC_BID_X * 256 + TIC_TID;
     if (c < C) {
         dbeta[c] += red[c];
         dgamma[c] += red[C + c];
+        red[c] = 0.f;       // consumed: left zero for the next launch that accumulates into it
+        red[C + c] = 0.f;
     }
+}
+static int batchnorm_bwd_impl(const void* dy, const void* y_or_null, const void* x, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta_mask, float* scratch2c, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M,
+                              int C, tic_stream_t stream) {
+    TIC_REQUIRE(dy && x && mean && rstd && gamma && scratch2c && dx && dgamma && dbeta, "batchnorm_bwd: null pointer");
+    TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_bwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
+    TIC_REQUIRE(!(y_or_null && beta_mask), "batchnorm_bwd: the ReLU mask comes from y OR from x, not both");
+    // scratch2c: zero on entry (caller, once), left zero by bn_param_grad_kernel
+    TIC_LAUNCH(bn_bwd_reduce_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null,
+               (const bf16_t*)x, mean, rstd, scratch2c, M, C, gamma, beta_mask ? beta_mask : gamma, beta_mask ? 1 : 0);
+    TIC_LAUNCH(bn_bwd_apply_kernel, ew_grid(M * (C / 8)), 256, 0, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null, (const bf16_t*)x, mean, rstd, gamma,
+               scratch2c, (bf16_t*)dx, (bf16_t*)dskip, skip_accumulate, M, C, beta_mask ? beta_mask : gamma, beta_mask ? 1 : 0);
+    TIC_LAUNCH(bn_param_grad_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, dgamma, dbeta, C);
+    return tic_after_launch("batchnorm_bwd");
 }
 extern "C" int tic_batchnorm_bwd(const void* dy, const void* y_or_null, const void* x, const float* mean, const float* rstd, const float* gamma,
                                  float* scratch2c, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M, int C,
                                  tic_stream_t stream) {
-    TIC_REQUIRE(dy && x && mean && rstd && gamma && scratch2c && dx && dgamma && dbeta, "batchnorm_bwd: null pointer");
-    TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_bwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
-    TIC_RT_MEMSET(scratch2c, 0, (size_t)2 * C * 4, stream);
-    TIC_LAUNCH(bn_bwd_reduce_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null,
-               (const bf16_t*)x, mean, rstd, scratch2c, M, C);
-    TIC_LAUNCH(bn_bwd_apply_kernel, ew_grid(M * (C / 8)), 256, 0, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null, (const bf16_t*)x, mean, rstd, gamma,
-               scratch2c, (bf16_t*)dx, (bf16_t*)dskip, skip_accumulate, M, C);
-    TIC_LAUNCH(bn_param_grad_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, dgamma, dbeta, C);
-    return tic_after_launch("batchnorm_bwd");
+    return batchnorm_bwd_impl(dy, y_or_null, x, mean, rstd, gamma, nullptr, scratch2c, dx, dskip, skip_accumulate, dgamma, dbeta, M, C, stream);
+}
+// backward of y = relu(bn(x)) WITHOUT a residual add: the ReLU mask is recomputed from x (bit-identical to the forward's), y is not read
+extern "C" int tic_batchnorm_bwd_relu(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                      float* scratch2c, void* dx, float* dgamma, float* dbeta, long M, int C, tic_stream_t stream) {
+    TIC_REQUIRE(beta, "batchnorm_bwd_relu: null beta");
+    return batchnorm_bwd_impl(dy, nullptr, x, mean, rstd, gamma, beta, scratch2c, dx, nullptr, 0, dgamma, dbeta, M, C, stream);
 }
 extern "C" int tic_maxpool3x3s2_fwd(const void* x, void* y, int B, int H, int W, int C, tic_stream_t stream) {
     TIC_REQUIRE(x && y && C % 8 == 0, "maxpool_fwd: need C %% 8 == 0");
