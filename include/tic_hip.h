@@ -191,6 +191,20 @@ int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, i
 int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* dw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                          int stride, int pad, tic_stream_t stream);
 int tic_conv_weight_grad(const float* dw_ohwi, float* grad_oihw, int Co, int Ci, int kh, int kw, tic_stream_t stream); /* grad += */
+/* tic_conv_weight_pack / tic_conv_weight_grad for a whole network in one launch each: `descs` points to n entries in DEVICE memory
+ * (the caller builds the table once; entries are consumed by blockIdx.y).  Same arithmetic per entry as the single calls. */
+typedef struct {
+    const float* w; /* OIHW fp32 */
+    void* out;      /* bf16 operand, layout by `transposed` as in tic_conv_weight_pack */
+    int Co, Ci, kh, kw, transposed, pad_;
+} TicConvPackDesc;
+typedef struct {
+    const float* dw; /* [Co, Kp] fp32 (tap-major) */
+    float* grad;     /* OIHW fp32, += */
+    int Co, Ci, kh, kw;
+} TicConvGradDesc;
+int tic_conv_weight_pack_many(const TicConvPackDesc* descs, int n, tic_stream_t stream);
+int tic_conv_weight_grad_many(const TicConvGradDesc* descs, int n, tic_stream_t stream);
 int tic_nchw_to_nhwc_bf16(const float* x, void* out_bf16, int B, int C, int H, int W, tic_stream_t stream);
 int tic_im2col_bf16(const void* x, void* col, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, tic_stream_t stream);
 int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, int accumulate,
@@ -212,6 +226,10 @@ int tic_batchnorm_bwd_relu(const void* dy, const void* x, const float* mean, con
                            float* scratch2c, void* dx, float* dgamma, float* dbeta, long M, int C, tic_stream_t stream);
 int tic_maxpool3x3s2_fwd(const void* x, void* y, int B, int H, int W, int C, tic_stream_t stream);                       /* model.py:152 */
 int tic_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, tic_stream_t stream);
+/* the same pool, with the window position (ky*3 + kx) of the first maximum saved as one byte per output element; the backward then
+ * reads only that and dy (no x, no y, no window re-scan) */
+int tic_maxpool3x3s2_fwd_idx(const void* x, void* y, void* idx_u8, int B, int H, int W, int C, tic_stream_t stream);
+int tic_maxpool3x3s2_bwd_idx(const void* idx_u8, const void* dy, void* dx, int B, int H, int W, int C, tic_stream_t stream);
 int tic_avgpool_fwd(const void* x, void* y, int B, int HW, int C, tic_stream_t stream);                                  /* model.py:164,222 */
 int tic_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, tic_stream_t stream);
 int tic_add_bf16(void* a, const void* b, long n, tic_stream_t stream); /* a += b */

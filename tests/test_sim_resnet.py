@@ -101,6 +101,12 @@ def test_batchnorm_and_pools_against_torch():
     dxp = torch.empty(B, H, W, C, dtype=torch.bfloat16)
     call("tic_maxpool3x3s2_bwd", ptr(xp), ptr(yp), ptr(dyp), ptr(dxp), B, H, W, C, None)
     torch.testing.assert_close(dxp.float(), xpr.grad.permute(0, 2, 3, 1), atol=0.02, rtol=0.01)
+    # the index form: same y, and a backward from (argmax position, dy) alone that equals the scanning backward bit for bit
+    yp2, pidx = torch.empty_like(yp), torch.empty(B, Ho, Wo, C, dtype=torch.uint8)
+    call("tic_maxpool3x3s2_fwd_idx", ptr(xp), ptr(yp2), ptr(pidx), B, H, W, C, None)
+    dxp2 = torch.empty_like(dxp)
+    call("tic_maxpool3x3s2_bwd_idx", ptr(pidx), ptr(dyp), ptr(dxp2), B, H, W, C, None)
+    assert torch.equal(yp2, yp) and torch.equal(dxp2, dxp) and int(pidx.max()) <= 8
     z = torch.empty(B, C, dtype=torch.bfloat16)
     call("tic_avgpool_fwd", ptr(xp), ptr(z), B, H * W, C, None)
     torch.testing.assert_close(z.float(), xp.float().mean((1, 2)), atol=0.01, rtol=0.01)

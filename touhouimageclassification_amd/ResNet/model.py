@@ -13,6 +13,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional
 
+import struct
+
 import torch
 import torch.nn as nn
 
@@ -128,22 +130,40 @@ class TicResNet(nn.Module):
         self._call("tic_gemm_nt_bf16", A.data_ptr(), Bw.data_ptr(), M, N, K, 0, None, out.data_ptr(), None, None, None, None, None, 0)
         return out
 
+    def _pack_variants(self, conv: _Conv):
+        """which bf16 operand forms of a conv weight the step reads: [Cout, Kp] (0) always; for the input gradient either the flipped
+        channel-transposed filter of the implicit GEMM (2) or the plain transpose (1)"""
+        if conv is self.conv1:
+            return (0,)   # the stem's input needs no gradient
+        return (0, 2) if (self._implicit(conv) and conv.stride == 1 and conv.cout % 64 == 0) else (0, 1)
+
+    def _refresh_packs(self, dev):
+        """re-pack EVERY conv weight in one launch when any fp32 weight changed (optimizer step, load_state_dict, .to()): persistent
+        output buffers + a descriptor table in device memory, rebuilt only when a pointer moves"""
+        convs = [m for m in self.modules() if isinstance(m, _Conv)]
+        key = (tuple(c.weight._version for c in convs), tuple(c.weight.data_ptr() for c in convs), dev)
+        st = self.__dict__.setdefault("_pack_state", {})
+        if st.get("key") == key:
+            return
+        ptrs = key[1:]
+        if st.get("ptrs") != ptrs:
+            descs = []
+            for c in convs:
+                packed = c.__dict__["_packed"] = {}
+                for t in self._pack_variants(c):
+                    shape = {0: (c.cout, c.kp), 1: (c.kp, c.cout), 2: (c.cin, c.k * c.k * c.cout)}[t]
+                    packed[t] = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+                    descs.append(struct.pack("<QQiiiiii", c.weight.data_ptr(), packed[t].data_ptr(), c.cout, c.cin, c.k, c.k, t, 0))
+            st["n"] = len(descs)
+            st["table"] = torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev)
+            st["ptrs"] = ptrs
+        self._call("tic_conv_weight_pack_many", st["table"].data_ptr(), st["n"])
+        st["key"] = key
+
     def _pack(self, conv: _Conv, transposed):
         """bf16 GEMM operand of a conv weight ([Cout, Kp], its transpose (1), or the flipped channel-transposed filter of the
-        implicit-GEMM input gradient (2)), re-packed only when the fp32 weight changed"""
-        w = conv.weight
-        key = (w._version, w.data_ptr(), w.device)
-        cache = conv.__dict__.setdefault("_packed", {})
-        if cache.get("key") != key:
-            cache.clear()
-            cache["key"] = key
-        if transposed not in cache:
-            kp = conv.kp
-            shape = {0: (conv.cout, kp), 1: (kp, conv.cout), 2: (conv.cin, conv.k * conv.k * conv.cout)}[int(transposed)]
-            out = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
-            self._call("tic_conv_weight_pack", w.data_ptr(), out.data_ptr(), conv.cout, conv.cin, conv.k, conv.k, int(transposed))
-            cache[transposed] = out
-        return cache[transposed]
+        implicit-GEMM input gradient (2)); kept fresh by _refresh_packs at the start of every forward"""
+        return conv.__dict__["_packed"][int(transposed)]
 
     @staticmethod
     def _implicit(conv: _Conv) -> bool:
@@ -225,8 +245,7 @@ class TicResNet(nn.Module):
                        conv.stride, conv.pad)
         else:
             self._call("tic_gemm_tn_bf16", dy.data_ptr(), col.data_ptr(), dw.data_ptr(), M, conv.cout, conv.kp)
-        self._call("tic_conv_weight_grad", dw.data_ptr(), self._grad_buf(conv.weight).data_ptr(), conv.cout, conv.cin, conv.k, conv.k)
-        if not need_dx:
+        if not need_dx:   # (the fold of dw into the OIHW .grad happens for all convs at once, at the end of the backward)
             return None
         if self._implicit(conv) and conv.stride == 1 and conv.cout % 64 == 0 and dx_accumulate_into is None:
             # input gradient = the same gather GEMM over dY with the flipped, channel-transposed filter
@@ -266,6 +285,7 @@ class TicResNet(nn.Module):
         if C != 3:
             raise ValueError(f"expected 3 input channels, got {C}")
         x = x.to(torch.float32).contiguous()
+        self._refresh_packs(x.device)
         tape: Dict = {"B": B, "blocks": []}
         xin = torch.empty(B, H, W, 3, dtype=torch.bfloat16, device=x.device)
         self._call("tic_nchw_to_nhwc_bf16", x.data_ptr(), xin.data_ptr(), B, 3, H, W)
@@ -273,8 +293,13 @@ class TicResNet(nn.Module):
         a0, m0, r0 = self._bn_fwd(self.bn1, c0, B * H1 * W1, None, True, train)
         Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
         h = torch.empty(B * Hp * Wp, 64, dtype=torch.bfloat16, device=x.device)
-        self._call("tic_maxpool3x3s2_fwd", a0.data_ptr(), h.data_ptr(), B, H1, W1, 64)
-        tape["stem"] = (col0, c0, a0, m0, r0, H, W, H1, W1, h)
+        pidx = None
+        if record:   # argmax positions for the backward (one byte per pooled element)
+            pidx = torch.empty(B * Hp * Wp, 64, dtype=torch.uint8, device=x.device)
+            self._call("tic_maxpool3x3s2_fwd_idx", a0.data_ptr(), h.data_ptr(), pidx.data_ptr(), B, H1, W1, 64)
+        else:
+            self._call("tic_maxpool3x3s2_fwd", a0.data_ptr(), h.data_ptr(), B, H1, W1, 64)
+        tape["stem"] = (col0, c0, a0, m0, r0, H, W, H1, W1, pidx)
         Hc, Wc = Hp, Wp
         for blk in self._blocks():
             rec = {"in": h, "H": Hc, "W": Wc}
@@ -339,11 +364,24 @@ class TicResNet(nn.Module):
             elif not folded:
                 self._call("tic_add_bf16", d.data_ptr(), dident.data_ptr(), d.numel())
             dh = d
-        col0, c0, a0, m0, r0, H, W, H1, W1, hpool = tape["stem"]
+        col0, c0, a0, m0, r0, H, W, H1, W1, pidx = tape["stem"]
         da0 = torch.empty_like(a0)
-        self._call("tic_maxpool3x3s2_bwd", a0.data_ptr(), hpool.data_ptr(), dh.data_ptr(), da0.data_ptr(), B, H1, W1, 64)
+        self._call("tic_maxpool3x3s2_bwd_idx", pidx.data_ptr(), dh.data_ptr(), da0.data_ptr(), B, H1, W1, 64)
         dc0 = self._bn_bwd(self.bn1, da0, None, c0, m0, r0, c0.shape[0], relu_from_x=True)
         self._conv_bwd(self.conv1, dc0, col0, B, H, W, need_dx=False)
+        self._fold_weight_grads(dev)
+
+    def _fold_weight_grads(self, dev):
+        """grad (OIHW) += dw scratch ([Cout, Kp], tap-major) for every conv in one launch"""
+        convs = [m for m in self.modules() if isinstance(m, _Conv)]
+        ptrs = (tuple(self._grad_buf(c.weight).data_ptr() for c in convs), tuple(c.__dict__["_dw_view"].data_ptr() for c in convs), dev)
+        st = self.__dict__.setdefault("_fold_state", {})
+        if st.get("ptrs") != ptrs:
+            descs = [struct.pack("<QQiiii", c.__dict__["_dw_view"].data_ptr(), self._grad_buf(c.weight).data_ptr(), c.cout, c.cin, c.k, c.k) for c in convs]
+            st["n"] = len(descs)
+            st["table"] = torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev)
+            st["ptrs"] = ptrs
+        self._call("tic_conv_weight_grad_many", st["table"].data_ptr(), st["n"])
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())

@@ -76,6 +76,8 @@ SIGNATURES = {
     "tic_mix_labels": ([P, P, I, I, F, P], I),
     "tic_conv_weight_pack": ([P, P, I, I, I, I, I, P], I),
     "tic_conv_weight_grad": ([P, P, I, I, I, I, P], I),
+    "tic_conv_weight_pack_many": ([P, I, P], I),
+    "tic_conv_weight_grad_many": ([P, I, P], I),
     "tic_conv_igemm_fwd": ([P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_conv_igemm_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_nchw_to_nhwc_bf16": ([P, P, I, I, I, I, P], I),
@@ -86,6 +88,8 @@ SIGNATURES = {
     "tic_batchnorm_bwd_relu": ([P, P, P, P, P, P, P, P, P, P, L, I, P], I),
     "tic_maxpool3x3s2_fwd": ([P, P, I, I, I, I, P], I),
     "tic_maxpool3x3s2_bwd": ([P, P, P, P, I, I, I, I, P], I),
+    "tic_maxpool3x3s2_fwd_idx": ([P, P, P, I, I, I, I, P], I),
+    "tic_maxpool3x3s2_bwd_idx": ([P, P, P, I, I, I, I, P], I),
     "tic_avgpool_fwd": ([P, P, I, I, I, P], I),
     "tic_avgpool_bwd": ([P, P, I, I, I, P], I),
     "tic_add_bf16": ([P, P, L, P], I),

@@ -18,7 +18,7 @@ struct ConvGeom {
 
 // OIHW fp32 -> [Co, Kp] bf16 with k = (ky*kw + kx)*Ci + c, zero padded; transposed == 1 writes [Kp, Co] (operand of the
 // explicit dgrad GEMM); transposed == 2 writes the implicit-GEMM dgrad filter [Ci][(ky', kx') * Co + o] = w[o][c][kh-1-ky'][kw-1-kx']
-__global__ void __launch_bounds__(256) weight_ohwi_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Co, ConvGeom g, int transposed) {
+TIC_DEV void weight_ohwi_body(const float* __restrict__ w, bf16_t* __restrict__ out, int Co, const ConvGeom& g, int transposed) {
     if (transposed == 2) {
         const long total2 = (long)g.Ci * g.kh * g.kw * Co;
         for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total2; i += (long)TIC_NBLK_X * 256) {
@@ -41,8 +41,34 @@ __global__ void __launch_bounds__(256) weight_ohwi_kernel(const float* __restric
         out[transposed ? ((long)k * Co + o) : i] = f2bf(v);
     }
 }
+__global__ void __launch_bounds__(256) weight_ohwi_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Co, ConvGeom g, int transposed) {
+    weight_ohwi_body(w, out, Co, g, transposed);
+}
+// every packed operand of a network in ONE launch: blockIdx.y = entry of a descriptor table in device memory (the per-conv launches
+// are ~6 us each and there are two per convolution and optimizer step: 105 launches = 0.62 ms of a 29 ms ResNet-50 step)
+struct ConvPackDesc {   // = TicConvPackDesc (include/tic_hip.h)
+    const float* w;
+    void* out;
+    int Co, Ci, kh, kw, transposed, pad_;
+};
+struct ConvGradDesc {   // = TicConvGradDesc
+    const float* dw;
+    float* grad;
+    int Co, Ci, kh, kw;
+};
+TIC_DEV ConvGeom weight_geom(int Ci, int kh, int kw) {
+    ConvGeom g;
+    g.B = 1; g.H = kh; g.W = kw; g.Ci = Ci; g.Ho = 1; g.Wo = 1; g.kh = kh; g.kw = kw; g.stride = 1; g.pad = 0;
+    g.K = kh * kw * Ci;
+    g.Kp = (g.K + 63) / 64 * 64;
+    return g;
+}
+__global__ void __launch_bounds__(256) weight_ohwi_many_kernel(const ConvPackDesc* __restrict__ descs) {
+    const ConvPackDesc d = descs[TIC_BID_Y];
+    weight_ohwi_body(d.w, (bf16_t*)d.out, d.Co, weight_geom(d.Ci, d.kh, d.kw), d.transposed);
+}
 // grad OIHW fp32 += dW [Co, Kp] (tap-major)
-__global__ void __launch_bounds__(256) weight_grad_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int Co, ConvGeom g) {
+TIC_DEV void weight_grad_oihw_body(const float* __restrict__ dw, float* __restrict__ grad, int Co, const ConvGeom& g) {
     const long total = (long)Co * g.K;
     for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
         // i indexes the OIHW gradient
@@ -53,6 +79,13 @@ __global__ void __launch_bounds__(256) weight_grad_oihw_kernel(const float* __re
         const int c = (int)(t % g.Ci), o = (int)(t / g.Ci);
         grad[i] += dw[(long)o * g.Kp + (ky * g.kw + kx) * g.Ci + c];
     }
+}
+__global__ void __launch_bounds__(256) weight_grad_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int Co, ConvGeom g) {
+    weight_grad_oihw_body(dw, grad, Co, g);
+}
+__global__ void __launch_bounds__(256) weight_grad_oihw_many_kernel(const ConvGradDesc* __restrict__ descs) {
+    const ConvGradDesc d = descs[TIC_BID_Y];
+    weight_grad_oihw_body(d.dw, d.grad, d.Co, weight_geom(d.Ci, d.kh, d.kw));
 }
 
 // x fp32 NCHW -> bf16 NHWC (the stem's input)
@@ -171,7 +204,24 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict_
     const int c0 = TIC_BID_X * 256 + tx * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c0 < C) {
-        for (long m = (long)TIC_BID_Y * R + ty; m < M; m += (long)TIC_NBLK_Y * R) {
+        // four rows per trip: four independent 16-byte loads in flight per thread (one per trip left the kernel latency-bound:
+        // 30 us for a 13 MB tensor)
+        const long st = (long)TIC_NBLK_Y * R;
+        long m = (long)TIC_BID_Y * R + ty;
+        for (; m + 3 * st < M; m += 4 * st) {
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(x + (m + u * st) * C + c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = bf2f((bf16_t)v[u][j]);
+                    s[j] += f;
+                    q[j] += f * f;
+                }
+        }
+        for (; m < M; m += st) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + m * C + c0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -273,11 +323,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
             sc[j] = rs[j] * gamma_m[c0 + j];
             sh[j] = beta_m[c0 + j] - mu[j] * sc[j];
         }
-        for (long m = (long)TIC_BID_Y * R + ty; m < M; m += (long)TIC_NBLK_Y * R) {
-            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + m * C + c0);
-            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + m * C + c0);
-            bf16x8 yv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (y) yv = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
+        const long st = (long)TIC_NBLK_Y * R;
+        auto row = [&](const bf16x8& d, const bf16x8& xv, const bf16x8& yv) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float dz = bf2f((bf16_t)d[j]);
@@ -287,6 +334,26 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
                 s[j] += dz;
                 q[j] += dz * (xf - mu[j]) * rs[j];
             }
+        };
+        long m = (long)TIC_BID_Y * R + ty;
+        for (; m + st < M; m += 2 * st) {   // two rows per trip: 4-6 independent 16-byte loads in flight per thread
+            bf16x8 d[2], xv[2], yv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                d[u] = *reinterpret_cast<const bf16x8*>(dy + (m + u * st) * C + c0);
+                xv[u] = *reinterpret_cast<const bf16x8*>(x + (m + u * st) * C + c0);
+                yv[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (y) yv[u] = *reinterpret_cast<const bf16x8*>(y + (m + u * st) * C + c0);
+            }
+            row(d[0], xv[0], yv[0]);
+            row(d[1], xv[1], yv[1]);
+        }
+        for (; m < M; m += st) {
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + m * C + c0);
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + m * C + c0);
+            bf16x8 yv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (y) yv = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
+            row(d, xv, yv);
         }
     }
 #pragma unroll
@@ -433,6 +500,76 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const bf16_t* __restri
                 for (int j = 0; j < 8; ++j) acc[j] += m[j] ? bf2f((bf16_t)dr[j]) : 0.f;
             }
         }
+        *reinterpret_cast<u32x4*>(dx + i * 8) =
+            u32x4{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
+    }
+}
+// The same pool with the window position (ky * 3 + kx, 0..8) of the FIRST maximum written beside y: the backward then needs neither x
+// nor y -- an input pixel asks the <= 4 windows that hold it whether it was their argmax (24 bytes per window from tensors a quarter of
+// the input's size, shared by up to 9 pixels) instead of re-scanning every window (maxpool_bwd_kernel: 0.9 ms at B = 256, 4.5 x the
+// time of its bytes).
+__global__ void __launch_bounds__(256) maxpool_fwd_idx_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, unsigned char* __restrict__ idx,
+                                                               int B, int H, int W, int C, int Ho, int Wo) {
+    const int cpr = C / 8;
+    const long total = (long)B * Ho * Wo * cpr;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int c0 = (int)(i % cpr) * 8;
+        long t = i / cpr;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho), b = (int)(t / Ho);
+        float mx[8];
+        uint32_t k8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mx[j] = -__builtin_huge_valf();
+            k8[j] = 0;
+        }
+        bool first = true;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((long)b * H + iy) * W + ix) * C + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = bf2f((bf16_t)v[j]);
+                    if (first || f > mx[j]) {   // strictly greater: ties keep the earlier position
+                        mx[j] = f;
+                        k8[j] = (uint32_t)(ky * 3 + kx);
+                    }
+                }
+                first = false;
+            }
+        }
+        const long o = (((long)b * Ho + oy) * Wo + ox) * C + c0;
+        *reinterpret_cast<u32x4*>(y + o) = u32x4{pack2bf(mx[0], mx[1]), pack2bf(mx[2], mx[3]), pack2bf(mx[4], mx[5]), pack2bf(mx[6], mx[7])};
+        *reinterpret_cast<u32x2*>(idx + o) = u32x2{k8[0] | (k8[1] << 8) | (k8[2] << 16) | (k8[3] << 24), k8[4] | (k8[5] << 8) | (k8[6] << 16) | (k8[7] << 24)};
+    }
+}
+__global__ void __launch_bounds__(256) maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                                               int B, int H, int W, int C, int Ho, int Wo) {
+    const int cpr = C / 8;
+    const long total = (long)B * H * W * cpr;
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+        const int c0 = (int)(i % cpr) * 8;
+        long t = i / cpr;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H), b = (int)(t / H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;   // windows holding row iy: 2 oy - 1 <= iy <= 2 oy + 1
+        for (int oy = oy0; oy <= oy1 && oy < Ho; ++oy)
+            for (int ox = ox0; ox <= ox1 && ox < Wo; ++ox) {
+                const long oo = (((long)b * Ho + oy) * Wo + ox) * C + c0;
+                const uint32_t me = (uint32_t)((iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1)));   // my position inside the window
+                const u32x2 k = *reinterpret_cast<const u32x2*>(idx + oo);
+                const bf16x8 dr = *reinterpret_cast<const bf16x8*>(dy + oo);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (((k[j >> 2] >> (8 * (j & 3))) & 0xffu) == me) ? bf2f((bf16_t)dr[j]) : 0.f;
+            }
         *reinterpret_cast<u32x4*>(dx + i * 8) =
             u32x4{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
     }

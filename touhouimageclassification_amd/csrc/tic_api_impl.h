@@ -773,6 +773,18 @@ extern "C" int tic_conv_weight_pack(const float* w_oihw, void* w16, int Co, int 
     TIC_LAUNCH(weight_ohwi_kernel, ew_grid((long)Co * g.Kp), 256, 0, stream, w_oihw, (bf16_t*)w16, Co, g, transposed);
     return tic_after_launch("conv_weight_pack");
 }
+// the same for a whole network: `descs` is a table of n entries in DEVICE memory (built once by the caller), one launch
+extern "C" int tic_conv_weight_pack_many(const TicConvPackDesc* descs, int n, tic_stream_t stream) {
+    TIC_REQUIRE(descs && n >= 1 && n <= 65535, "conv_weight_pack_many: bad argument");
+    static_assert(sizeof(ConvPackDesc) == sizeof(TicConvPackDesc) && sizeof(ConvGradDesc) == sizeof(TicConvGradDesc), "descriptor layouts");
+    TIC_LAUNCH(weight_ohwi_many_kernel, dim3(64, (unsigned)n), 256, 0, stream, (const ConvPackDesc*)descs);
+    return tic_after_launch("conv_weight_pack_many");
+}
+extern "C" int tic_conv_weight_grad_many(const TicConvGradDesc* descs, int n, tic_stream_t stream) {
+    TIC_REQUIRE(descs && n >= 1 && n <= 65535, "conv_weight_grad_many: bad argument");
+    TIC_LAUNCH(weight_grad_oihw_many_kernel, dim3(64, (unsigned)n), 256, 0, stream, (const ConvGradDesc*)descs);
+    return tic_after_launch("conv_weight_grad_many");
+}
 // implicit-GEMM convolution (3x3 and friends with Cin % 64 == 0): y[M = B*Ho*Wo, Cout] = gather(x) . Wpack^T
 extern "C" int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                                   int stride, int pad, tic_stream_t stream) {
@@ -848,9 +860,14 @@ extern "C" int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, 
     TIC_LAUNCH(col2im_kernel, ew_grid((long)B * H * W * (Ci / 8)), 256, 0, stream, (const bf16_t*)dcol, (bf16_t*)dx, g, accumulate);
     return tic_after_launch("col2im");
 }
-static int bn_rows(long M) {   // row splits of the column-reduction kernels: up to 4 blocks per CU at the big layers
-    long r = (M + 255) / 256;
-    return (int)(r > 1024 ? 1024 : (r < 1 ? 1 : r));
+// row splits of the column-reduction kernels (grid.y).  Every block ends with 2 C atomics onto the same 2 C addresses, and adds to ONE
+// address serialise at ~11 ns each: grid.y = 2048 cost 20 us per launch in atomics alone, so at most 512 (the kernels keep 4 / 2 rows
+// per thread in flight instead); and no more than leave every thread 4 rows.  A block covers R = 256 / min(C/8, 32) rows per trip.
+static int bn_rows(long M, int C) {
+    const int cpb = (C / 8) < 32 ? (C / 8) : 32, R = 256 / cpb;
+    long want = 512, most = (M + 4L * R - 1) / (4L * R);
+    if (want > most) want = most;
+    return (int)(want < 1 ? 1 : want);
 }
 extern "C" int tic_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                  int64_t* num_batches, float* mean, float* rstd, float* scratch2c, const void* identity, void* y, long M, int C,
@@ -858,7 +875,7 @@ extern "C" int tic_batchnorm_fwd(const void* x, const float* gamma, const float*
     TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && scratch2c && y, "batchnorm_fwd: null pointer");
     TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_fwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
     if (train) {   // scratch2c: zero on entry (caller, once), left zero by bn_finalize_kernel
-        TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, scratch2c, M, C);
+        TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, bn_rows(M, C)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, scratch2c, M, C);
     }
     TIC_LAUNCH(bn_finalize_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, mean, rstd, running_mean, running_var, (long long*)num_batches, M, C, eps,
                momentum, train);
@@ -881,7 +898,7 @@ static int batchnorm_bwd_impl(const void* dy, const void* y_or_null, const void*
     TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_bwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
     TIC_REQUIRE(!(y_or_null && beta_mask), "batchnorm_bwd: the ReLU mask comes from y OR from x, not both");
     // scratch2c: zero on entry (caller, once), left zero by bn_param_grad_kernel
-    TIC_LAUNCH(bn_bwd_reduce_kernel, dim3((C + 255) / 256, bn_rows(M)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null,
+    TIC_LAUNCH(bn_bwd_reduce_kernel, dim3((C + 255) / 256, bn_rows(M, C)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null,
                (const bf16_t*)x, mean, rstd, scratch2c, M, C, gamma, beta_mask ? beta_mask : gamma, beta_mask ? 1 : 0);
     TIC_LAUNCH(bn_bwd_apply_kernel, ew_grid(M * (C / 8)), 256, 0, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null, (const bf16_t*)x, mean, rstd, gamma,
                scratch2c, (bf16_t*)dx, (bf16_t*)dskip, skip_accumulate, M, C, beta_mask ? beta_mask : gamma, beta_mask ? 1 : 0);
@@ -910,6 +927,18 @@ extern "C" int tic_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     TIC_LAUNCH(maxpool_bwd_kernel, ew_grid((long)B * H * W * (C / 8)), 256, 0, stream, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, Ho, Wo);
     return tic_after_launch("maxpool_bwd");
+}
+extern "C" int tic_maxpool3x3s2_fwd_idx(const void* x, void* y, void* idx_u8, int B, int H, int W, int C, tic_stream_t stream) {
+    TIC_REQUIRE(x && y && idx_u8 && C % 8 == 0, "maxpool_fwd_idx: null pointer or C %% 8 != 0");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    TIC_LAUNCH(maxpool_fwd_idx_kernel, ew_grid((long)B * Ho * Wo * (C / 8)), 256, 0, stream, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)idx_u8, B, H, W, C, Ho, Wo);
+    return tic_after_launch("maxpool_fwd_idx");
+}
+extern "C" int tic_maxpool3x3s2_bwd_idx(const void* idx_u8, const void* dy, void* dx, int B, int H, int W, int C, tic_stream_t stream) {
+    TIC_REQUIRE(idx_u8 && dy && dx && C % 8 == 0, "maxpool_bwd_idx: null pointer or C %% 8 != 0");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    TIC_LAUNCH(maxpool_bwd_idx_kernel, ew_grid((long)B * H * W * (C / 8)), 256, 0, stream, (const unsigned char*)idx_u8, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, Ho, Wo);
+    return tic_after_launch("maxpool_bwd_idx");
 }
 extern "C" int tic_avgpool_fwd(const void* x, void* y, int B, int HW, int C, tic_stream_t stream) {
     TIC_REQUIRE(x && y && B >= 1 && HW >= 1, "avgpool_fwd: bad argument");
