@@ -37,6 +37,7 @@ const char* tic_last_error_string(void);
  *   "gemm_tile"  0 (auto) | 128 | 256       which NT / TN tile family to use
  *   "tn_streamk" 1 (256 shares) | 0 | n     stream-K split of the grouped dW launch
  *   "tn_phase"   1 | 0                      phase-aligned vs flat stream-K split
+ *   "tn_parts"   -1 (auto) | 0 | 2..8       tile counts without a phase-aligned split (ViT-B: 108): every tile in n equal row parts (auto: 256 / tiles) | flat stream-K
  *   "tn_mfma"    0 (auto) | 16 | 32         MFMA shape of the grouped dW stream-K launch (16x16x32 for long reductions, else 32x32x16)
  *   "tn_block"   -1 (auto) | 0 | n          tile-walk block width of that launch (XCD-sized blocks | row-major | fixed)
  *   "gemm_big_tiles" 128                    fewest 256x256 tiles for which the 256x256 NT kernel is chosen (below: the 128x128 kernel)

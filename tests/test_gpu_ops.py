@@ -79,7 +79,8 @@ def test_gemm_nt256_pipelined(env, M, N, K):
 
 
 @pytest.mark.parametrize("M,shapes", [(200, [(256, 256)]), (12608, [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 1024)]),
-                                      (1970, [(768, 3072), (3072, 768), (768, 768), (2304, 768)])])
+                                      (1970, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),
+                                      (12608, [(768, 3072), (3072, 768), (768, 768), (2304, 768)])])   # ViT-B: 108 tiles -> the equal-parts split (2 x 108 workgroups)
 def test_gemm_tn_group(env, M, shapes):
     kc.check_gemm_tn_group(env, M, shapes)
     from touhouimageclassification_amd._lib import call
@@ -90,10 +91,16 @@ def test_gemm_tn_group(env, M, shapes):
             for sk in (0, 1, 7, 100):   # full-M tiles; 256 / 7 / 100 stream-K shares (partial tiles, shares crossing problems)
                 call("tic_set_option", b"tn_streamk", sk)
                 kc.check_gemm_tn_group(env, M, shapes)
+            call("tic_set_option", b"tn_streamk", 1)
+            for parts in (0, 2, 3):         # flat stream-K / every tile in 2 / 3 equal row parts (where the tile count has no phase-aligned split)
+                call("tic_set_option", b"tn_parts", parts)
+                kc.check_gemm_tn_group(env, M, shapes)
+            call("tic_set_option", b"tn_parts", -1)
     finally:
         call("tic_set_option", b"gemm_tile", 0)
         call("tic_set_option", b"tn_streamk", 1)
         call("tic_set_option", b"tn_mfma", 0)
+        call("tic_set_option", b"tn_parts", -1)
 
 
 @pytest.mark.parametrize("S,H,W", [(32, 40, 48), (224, 256, 256)])

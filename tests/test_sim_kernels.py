@@ -113,6 +113,23 @@ def test_gemm_tn_group_phase_aligned_split(env, mfma):
         call("tic_set_option", b"tn_mfma", 0)
 
 
+@pytest.mark.parametrize("parts", [2, 3])
+def test_gemm_tn_group_equal_parts_split(env, parts):
+    """9 tiles (not a multiple of 8: XCD runs of 2 and 1 tiles), every tile cut into 2 / 3 equal row ranges; 333 rows = 6 steps"""
+    call("tic_set_option", b"gemm_tile", 256)
+    call("tic_set_option", b"tn_streamk", 16)
+    call("tic_set_option", b"tn_parts", parts)
+    try:
+        for mfma in (16, 32):
+            call("tic_set_option", b"tn_mfma", mfma)
+            kc.check_gemm_tn_group(env, 333, [(512, 512), (256, 1024), (256, 256)])
+    finally:
+        call("tic_set_option", b"gemm_tile", 0)
+        call("tic_set_option", b"tn_streamk", 1)
+        call("tic_set_option", b"tn_parts", -1)
+        call("tic_set_option", b"tn_mfma", 0)
+
+
 @pytest.mark.parametrize("M,N,K,pgrid", [(600, 512, 192, 2), (300, 256, 128, 1)])
 def test_persistent_nt_kernel_is_bit_identical(env, M, N, K, pgrid):
     """6 tiles on 2 workgroups (3 each, odd K-tile count -> a zero-fill K tile, ragged last row tile) / 2 tiles on 1 workgroup"""

@@ -15,9 +15,10 @@ for kv in filter(None, os.environ.get("TIC_PRESET", "").split(",")):   # other k
     call("tic_set_option", k.encode(), int(v))
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 332
 dev = torch.device("cuda")
-m = ViT(120, pretrained=False, model_name="google/vit-large-patch16-224").to(dev)
+MODEL = {"large": ("google/vit-large-patch16-224", 120), "base": ("google/vit-base-patch16-224", 10)}[os.environ.get("TIC_MODEL", "large")]   # TIC_MODEL=base: BASELINE config 2
+m = ViT(MODEL[1], pretrained=False, model_name=MODEL[0]).to(dev)
 opt = FusedAdamW(m, lr=1e-5, weight_decay=0.01)
-x = torch.randn(B, 3, 224, 224, device=dev); y = torch.randint(0, 120, (B,), device=dev)
+x = torch.randn(B, 3, 224, 224, device=dev); y = torch.randint(0, MODEL[1], (B,), device=dev)
 for _ in range(4): fused_train_step(m, opt, x, y, None)
 acc = {va: [], vb: []}
 for rnd in range(4):

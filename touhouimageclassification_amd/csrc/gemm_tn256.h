@@ -554,35 +554,55 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
 //   time and so do the tail CUs (lock-step row slabs are what the L2 / Infinity Cache can share: the flat split below
 //   fetched 2x the bytes of the lock-step kernel because its shares start at 256 different row offsets).
 // s_main == 0 -- FLAT split: the flattened (tile, step) space cut into gridDim.x equal contiguous shares.
+// s_main < 0  -- EQUAL PARTS (tile counts the phase-aligned split cannot take, e.g. ViT-B: 108 tiles): P = -s_main workgroups per tile,
+//   each the same row range [part S/P, (part+1) S/P) of its tile; the tiles are dealt to the XCDs in contiguous runs of q or q + 1.
+//   2 x 108 = 216 workgroups leave 40 CUs idle, but the workgroups of a part sweep the same rows at the same time (the flat split's
+//   256 shares start at 256 different row offsets and fetch every panel twice).
 // body shared by the two kernel names below (a macro, not a function: passing the by-value kernel argument struct on to a
 // function makes hipcc copy it to scratch -- +136 B/lane, +21 VGPRs, 8 % slower)
 #define TN256_STREAMK_BODY(SEG) \
-    const bf16_t *Ap, *Bp; \
-    float* Cp; \
-    int N, K, n0, k0; \
-    if (s_main > 0) { \
+    /* every mode is reduced to "nseg segments (tile, [a, b))" so that the pipelined tile routine is inlined at ONE call site: a second, \
+       third and fourth site cost registers each, and the fourth (equal parts) tipped the kernel into 184 spilled registers */ \
+    int nseg = 0, tile0 = 0, a0 = 0, b_last = nsteps, a_rest = 0; \
+    if (s_main < 0) {   /* EQUAL PARTS: every tile is cut into P = -s_main row ranges, one workgroup each (P * tiles <= 256) */ \
+        const int P = -s_main, xcd = TIC_BID_X & 7, idx = TIC_BID_X >> 3; \
+        const int q = gp.total_tiles >> 3, r = gp.total_tiles & 7, txm = q + (r ? 1 : 0);   /* tiles of an XCD: q or q + 1 */ \
+        const int tx = q + (xcd < r ? 1 : 0), part = idx / txm, ti = idx - part * txm; \
+        const int per = (nsteps + P - 1) / P; \
+        tile0 = xcd * q + (xcd < r ? xcd : r) + ti; \
+        a0 = part * per; \
+        b_last = (a0 + per < nsteps) ? a0 + per : nsteps; \
+        nseg = (ti < tx && part < P && a0 < b_last) ? 1 : 0; \
+    } else if (s_main > 0) { \
         const int xcd = TIC_BID_X & 7, idx = TIC_BID_X >> 3;   /* blocks b, b+8, ... share an XCD (speed only, never correctness) */ \
         if (idx < tpx) { \
-            tn_tile_lookup(gp, xcd * tpx + idx, Ap, Bp, Cp, N, K, n0, k0); \
-            SEG<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, s_main); \
+            tile0 = xcd * tpx + idx; \
+            a0 = 0; \
+            b_last = s_main; \
+            nseg = 1; \
         } else { \
-            for (int j = 0; j < tail_each; ++j) { \
-                tn_tile_lookup(gp, xcd * tpx + (idx - tpx) * tail_each + j, Ap, Bp, Cp, N, K, n0, k0); \
-                SEG<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s_main, nsteps); \
-            } \
+            tile0 = xcd * tpx + (idx - tpx) * tail_each; \
+            a0 = a_rest = s_main; \
+            b_last = nsteps; \
+            nseg = tail_each; \
         } \
-        return; \
+    } else { \
+        const long total_units = (long)gp.total_tiles * nsteps; \
+        const int u0 = (int)(total_units * TIC_BID_X / TIC_NBLK_X), u1 = (int)(total_units * (TIC_BID_X + 1) / TIC_NBLK_X); \
+        if (u1 > u0) { \
+            const int tile_l = (u1 - 1) / nsteps; \
+            tile0 = u0 / nsteps; \
+            a0 = u0 - tile0 * nsteps; \
+            b_last = u1 - tile_l * nsteps; \
+            nseg = tile_l - tile0 + 1; \
+        } \
     } \
-    const long total_units = (long)gp.total_tiles * nsteps; \
-    int u = (int)(total_units * TIC_BID_X / TIC_NBLK_X); \
-    const int u1 = (int)(total_units * (TIC_BID_X + 1) / TIC_NBLK_X); \
-    while (u < u1) {   /* wave-uniform */ \
-        const int tile = u / nsteps, s0 = u - tile * nsteps; \
-        int s1 = s0 + (u1 - u); \
-        if (s1 > nsteps) s1 = nsteps; \
-        tn_tile_lookup(gp, tile, Ap, Bp, Cp, N, K, n0, k0); \
-        SEG<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, s0, s1); \
-        u += s1 - s0; \
+    for (int it = 0; it < nseg; ++it) {   /* wave-uniform */ \
+        const bf16_t *Ap, *Bp; \
+        float* Cp; \
+        int N, K, n0, k0; \
+        tn_tile_lookup(gp, tile0 + it, Ap, Bp, Cp, N, K, n0, k0); \
+        SEG<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, it == 0 ? a0 : a_rest, it == nseg - 1 ? b_last : nsteps); \
     }
 
 // the grouped launch of one transformer block (the step's dominant kernel: bench.py times exactly these launches) ...

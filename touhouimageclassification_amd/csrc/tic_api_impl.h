@@ -71,6 +71,7 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
     return TIC_OK;
 }
 #endif
+static int g_opt_tn_parts = -1;           // grouped dW without a phase-aligned split: -1 auto (256 / tiles equal row parts per tile), 0 never (flat stream-K), n forced
 static int g_opt_tn_streamk_min_steps = 128;   // grouped dW: fewest 64-row steps for which the stream-K split is chosen
 static int g_opt_ln_bwd_blocks = 512;    // LayerNorm backward: most blocks per launch
 static int g_opt_ln_bwd_rows = 2;        // LayerNorm backward: fewest rows per wave (bounds the number of dgamma / dbeta atomic rows)
@@ -107,6 +108,10 @@ extern "C" int tic_set_option(const char* name, int value) {
     }
     if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
         g_opt_nt = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "tn_parts") && value >= -1 && value <= 8) {
+        g_opt_tn_parts = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "tn_streamk_min_steps") && value >= 1 && value <= (1 << 20)) {
@@ -454,18 +459,31 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
                     if (s_main < 1 || s_main >= nsteps) s_main = 0;
                 }
             }
+            // no phase-aligned split for this tile count: equal parts when 2..8 of them fit the chip and each keeps >= 64 steps
+            int grid_wg = (int)shares;
+            if (s_main == 0 && (g_opt_tn_parts > 0 || (g_opt_tn_parts < 0 && g_opt_tn_streamk == 1))) {
+                const bool forced = g_opt_tn_parts > 0;   // tests
+                int P = forced ? g_opt_tn_parts : (int)(256 / t);
+                if (P > 8) P = 8;
+                const int txm = (t >> 3) + ((t & 7) ? 1 : 0);
+                // auto: only where each part keeps >= 64 steps and >= 3/4 of the CUs get one
+                if (P >= 2 && 8 * txm * P <= 320 && (forced || (nsteps / P >= 64 && (long)P * t >= 192))) {
+                    s_main = -P;
+                    grid_wg = 8 * txm * P;
+                }
+            }
             if (force256) {   // single-problem route: same code, own kernel name, not part of the live timer
                 TIC_RT_MAX_LDS(gemm_tn256_streamk_single_kernel, G256_LDS_BYTES);
-                TIC_LAUNCH(gemm_tn256_streamk_single_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
+                TIC_LAUNCH(gemm_tn256_streamk_single_kernel, grid_wg, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
                 return tic_after_launch("gemm_tn(stream-K)");
             }
             TIC_RT_TIMER_MARK(0, stream);
             if (g_opt_tn_mfma == 32 || (g_opt_tn_mfma == 0 && nsteps < 512)) {
                 TIC_RT_MAX_LDS(gemm_tn256_streamk_mfma32_kernel, G256_LDS_BYTES);
-                TIC_LAUNCH(gemm_tn256_streamk_mfma32_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
+                TIC_LAUNCH(gemm_tn256_streamk_mfma32_kernel, grid_wg, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
             } else {
                 TIC_RT_MAX_LDS(gemm_tn256_streamk_kernel, G256_LDS_BYTES);
-                TIC_LAUNCH(gemm_tn256_streamk_kernel, (int)shares, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
+                TIC_LAUNCH(gemm_tn256_streamk_kernel, grid_wg, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
             }
             TIC_RT_TIMER_MARK(1, stream);
             return tic_after_launch("gemm_tn_group(stream-K)");
