@@ -43,6 +43,10 @@ if "WORLD_SIZE" not in os.environ and a.gpus > 1:   # start our own ranks BEFORE
 
 import torch.distributed as dist  # noqa: E402
 from touhouimageclassification_amd.ResNet import model as rm  # noqa: E402
+from touhouimageclassification_amd._lib import call as _call  # noqa: E402
+for _kv in filter(None, os.environ.get("TIC_PRESET", "").split(",")):   # knobs held for the run: TIC_PRESET=gemm_tile=128,...
+    _k, _v = _kv.split("=")
+    _call("tic_set_option", _k.encode(), int(_v))
 
 
 def train_flops_per_image(model, image: int) -> float:

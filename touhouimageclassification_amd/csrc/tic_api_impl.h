@@ -71,6 +71,7 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
     return TIC_OK;
 }
 #endif
+static int g_opt_tn_split_wgs = 1024;    // split-M weight-gradient kernels (128x128 tiles): workgroups aimed at (every split adds its tile to C with fp32 atomics)
 static int g_opt_tn_parts = -1;           // grouped dW without a phase-aligned split: -1 auto (256 / tiles equal row parts per tile), 0 never (flat stream-K), n forced
 static int g_opt_tn_streamk_min_steps = 128;   // grouped dW: fewest 64-row steps for which the stream-K split is chosen
 static int g_opt_ln_bwd_blocks = 512;    // LayerNorm backward: most blocks per launch
@@ -108,6 +109,10 @@ extern "C" int tic_set_option(const char* name, int value) {
     }
     if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
         g_opt_nt = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "tn_split_wgs") && value >= 64 && value <= 8192) {
+        g_opt_tn_split_wgs = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "tn_parts") && value >= -1 && value <= 8) {
@@ -385,7 +390,7 @@ extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, i
     TIC_REQUIRE(((double)M + 64.0) * (N > K ? N : K) * 2.0 < 4294967296.0, "gemm_tn: operand exceeds the 4 GiB buffer-resource range");
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     // split the M reduction so that ~4 workgroups per CU are in flight (256 CUs)
-    int split = (1024 + tiles - 1) / tiles;
+    int split = (g_opt_tn_split_wgs + tiles - 1) / tiles;
     const int max_split = (M + 63) / 64;
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
@@ -836,7 +841,7 @@ extern "C" int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* d
                 "conv_igemm_wgrad: tensor exceeds the 32-bit offset / 2^24 row range");
     const int M = (int)Ml;
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    int split = (1024 + tiles - 1) / tiles;
+    int split = (g_opt_tn_split_wgs + tiles - 1) / tiles;
     const int max_split = (M + 63) / 64;
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;
