@@ -19,14 +19,62 @@ struct ConvGeom {
 // OIHW fp32 -> [Co, Kp] bf16 with k = (ky*kw + kx)*Ci + c, zero padded; transposed == 1 writes [Kp, Co] (operand of the
 // explicit dgrad GEMM); transposed == 2 writes the implicit-GEMM dgrad filter [Ci][(ky', kx') * Co + o] = w[o][c][kh-1-ky'][kw-1-kx']
 TIC_DEV void weight_ohwi_body(const float* __restrict__ w, bf16_t* __restrict__ out, int Co, const ConvGeom& g, int transposed) {
+    const int taps = g.kh * g.kw;
+    if (transposed == 2 && Co % 8 == 0) {   // [Ci][tap' * Co + o]: 8 consecutive o per thread, one 16-byte store
+        const int oc = Co / 8;
+        const long total2 = (long)g.Ci * taps * oc;
+        for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total2; i += (long)TIC_NBLK_X * 256) {
+            const int o0 = (int)(i % oc) * 8;
+            long t = i / oc;
+            const int tap = (int)(t % taps), c = (int)(t / taps);
+            const int ky = g.kh - 1 - tap / g.kw, kx = g.kw - 1 - tap % g.kw;
+            const float* src = w + (((long)o0 * g.Ci + c) * g.kh + ky) * g.kw + kx;
+            const long os = (long)g.Ci * taps;   // elements between consecutive output channels
+            *reinterpret_cast<u32x4*>(out + i * 8) = u32x4{pack2bf(src[0], src[os]), pack2bf(src[2 * os], src[3 * os]),
+                                                           pack2bf(src[4 * os], src[5 * os]), pack2bf(src[6 * os], src[7 * os])};
+        }
+        return;
+    }
     if (transposed == 2) {
-        const long total2 = (long)g.Ci * g.kh * g.kw * Co;
+        const long total2 = (long)g.Ci * taps * Co;
         for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total2; i += (long)TIC_NBLK_X * 256) {
             const int o = (int)(i % Co);
             long t = i / Co;
-            const int tap = (int)(t % (g.kh * g.kw)), c = (int)(t / (g.kh * g.kw));
+            const int tap = (int)(t % taps), c = (int)(t / taps);
             const int ky = g.kh - 1 - tap / g.kw, kx = g.kw - 1 - tap % g.kw;
             out[i] = f2bf(w[(((long)o * g.Ci + c) * g.kh + ky) * g.kw + kx]);
+        }
+        return;
+    }
+    if (transposed == 1 && Co % 8 == 0) {   // [Kp, Co]: 8 consecutive o per thread for one k
+        const int oc = Co / 8;
+        const long total1 = (long)g.Kp * oc;
+        for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total1; i += (long)TIC_NBLK_X * 256) {
+            const int o0 = (int)(i % oc) * 8, k = (int)(i / oc);
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (k < g.K) {
+                const int tap = k / g.Ci, c = k - tap * g.Ci, ky = tap / g.kw, kx = tap - ky * g.kw;
+                const float* src = w + (((long)o0 * g.Ci + c) * g.kh + ky) * g.kw + kx;
+                const long os = (long)g.Ci * taps;
+                v = u32x4{pack2bf(src[0], src[os]), pack2bf(src[2 * os], src[3 * os]), pack2bf(src[4 * os], src[5 * os]), pack2bf(src[6 * os], src[7 * os])};
+            }
+            *reinterpret_cast<u32x4*>(out + i * 8) = v;
+        }
+        return;
+    }
+    if (transposed == 0 && g.Ci % 8 == 0) {   // [Co, Kp]: 8 consecutive channels of one tap per thread (Kp == K when Ci % 8 == 0 and K % 64 == 0, else zero tail)
+        const int kc = g.Kp / 8;
+        const long total0 = (long)Co * kc;
+        for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total0; i += (long)TIC_NBLK_X * 256) {
+            const int o = (int)(i / kc), k0 = (int)(i - (long)o * kc) * 8;
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (k0 < g.K) {
+                const int tap = k0 / g.Ci, c0 = k0 - tap * g.Ci, ky = tap / g.kw, kx = tap - ky * g.kw;
+                const float* src = w + (((long)o * g.Ci + c0) * g.kh + ky) * g.kw + kx;
+                v = u32x4{pack2bf(src[0], src[taps]), pack2bf(src[2 * taps], src[3 * taps]), pack2bf(src[4 * taps], src[5 * taps]),
+                          pack2bf(src[6 * taps], src[7 * taps])};
+            }
+            *reinterpret_cast<u32x4*>(out + i * 8) = v;
         }
         return;
     }
