@@ -231,6 +231,12 @@ int tic_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx,
  * reads only that and dy (no x, no y, no window re-scan) */
 int tic_maxpool3x3s2_fwd_idx(const void* x, void* y, void* idx_u8, int B, int H, int W, int C, tic_stream_t stream);
 int tic_maxpool3x3s2_bwd_idx(const void* idx_u8, const void* dy, void* dx, int B, int H, int W, int C, tic_stream_t stream);
+/* the stem's tail fused (model.py:150-152, bn1 -> relu -> maxpool): y_pool = maxpool3x3/2(relu(bn(x))) + argmax positions without
+ * storing relu(bn(x)); bit-identical to tic_batchnorm_fwd(relu) + tic_maxpool3x3s2_fwd_idx.  Backward: tic_maxpool3x3s2_bwd_idx, then
+ * tic_batchnorm_bwd_relu on x */
+int tic_bn_relu_maxpool_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                            float* mean, float* rstd, float* scratch2c, void* y_pool, void* idx_u8_or_null, int B, int H, int W, int C, float eps,
+                            float momentum, int train, tic_stream_t stream);
 int tic_avgpool_fwd(const void* x, void* y, int B, int HW, int C, tic_stream_t stream);                                  /* model.py:164,222 */
 int tic_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, tic_stream_t stream);
 int tic_add_bf16(void* a, const void* b, long n, tic_stream_t stream); /* a += b */

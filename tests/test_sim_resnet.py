@@ -107,6 +107,19 @@ def test_batchnorm_and_pools_against_torch():
     dxp2 = torch.empty_like(dxp)
     call("tic_maxpool3x3s2_bwd_idx", ptr(pidx), ptr(dyp), ptr(dxp2), B, H, W, C, None)
     assert torch.equal(yp2, yp) and torch.equal(dxp2, dxp) and int(pidx.max()) <= 8
+    # the stem's fused tail: bn -> relu -> maxpool (+ positions), bit-identical to the two-kernel sequence
+    xs = bf(torch.randn(B * H * W, C) * 2 + 0.3)
+    rm2, rv2, nb2 = torch.zeros(C), torch.ones(C), torch.tensor(0)
+    rm3, rv3, nb3 = torch.zeros(C), torch.ones(C), torch.tensor(0)
+    mA, rA, mB, rB = torch.empty(C), torch.empty(C), torch.empty(C), torch.empty(C)
+    aA = torch.empty(B * H * W, C, dtype=torch.bfloat16)
+    call("tic_batchnorm_fwd", ptr(xs), ptr(gamma), ptr(beta), ptr(rm2), ptr(rv2), ptr(nb2), ptr(mA), ptr(rA), ptr(scr), None, ptr(aA), B * H * W, C, 1e-5, 0.1, 1, 1, None)
+    hA, iA = torch.empty(B, Ho, Wo, C, dtype=torch.bfloat16), torch.empty(B, Ho, Wo, C, dtype=torch.uint8)
+    call("tic_maxpool3x3s2_fwd_idx", ptr(aA), ptr(hA), ptr(iA), B, H, W, C, None)
+    hB, iB = torch.empty_like(hA), torch.empty_like(iA)
+    call("tic_bn_relu_maxpool_fwd", ptr(xs), ptr(gamma), ptr(beta), ptr(rm3), ptr(rv3), ptr(nb3), ptr(mB), ptr(rB), ptr(scr), ptr(hB), ptr(iB), B, H, W, C, 1e-5, 0.1, 1, None)
+    assert torch.equal(hA, hB) and torch.equal(iA, iB) and torch.equal(mA, mB) and torch.equal(rA, rB) and torch.equal(rm2, rm3) and torch.equal(rv2, rv3)
+    assert float(scr.abs().max()) == 0.0
     z = torch.empty(B, C, dtype=torch.bfloat16)
     call("tic_avgpool_fwd", ptr(xp), ptr(z), B, H * W, C, None)
     torch.testing.assert_close(z.float(), xp.float().mean((1, 2)), atol=0.01, rtol=0.01)

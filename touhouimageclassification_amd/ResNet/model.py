@@ -290,16 +290,18 @@ class TicResNet(nn.Module):
         xin = torch.empty(B, H, W, 3, dtype=torch.bfloat16, device=x.device)
         self._call("tic_nchw_to_nhwc_bf16", x.data_ptr(), xin.data_ptr(), B, 3, H, W)
         c0, col0, H1, W1 = self._conv_fwd(self.conv1, xin, B, H, W)
-        a0, m0, r0 = self._bn_fwd(self.bn1, c0, B * H1 * W1, None, True, train)
+        # bn1 -> relu -> maxpool in one piece: relu(bn(c0)) (411 MB at B = 256) is never stored; the backward needs c0, the batch
+        # statistics and one byte of argmax position per pooled element
         Hp, Wp = (H1 + 2 - 3) // 2 + 1, (W1 + 2 - 3) // 2 + 1
-        h = torch.empty(B * Hp * Wp, 64, dtype=torch.bfloat16, device=x.device)
-        pidx = None
-        if record:   # argmax positions for the backward (one byte per pooled element)
-            pidx = torch.empty(B * Hp * Wp, 64, dtype=torch.uint8, device=x.device)
-            self._call("tic_maxpool3x3s2_fwd_idx", a0.data_ptr(), h.data_ptr(), pidx.data_ptr(), B, H1, W1, 64)
-        else:
-            self._call("tic_maxpool3x3s2_fwd", a0.data_ptr(), h.data_ptr(), B, H1, W1, 64)
-        tape["stem"] = (col0, c0, a0, m0, r0, H, W, H1, W1, pidx)
+        dev = x.device
+        m0, r0 = torch.empty(64, device=dev), torch.empty(64, device=dev)
+        h = torch.empty(B * Hp * Wp, 64, dtype=torch.bfloat16, device=dev)
+        pidx = torch.empty(B * Hp * Wp, 64, dtype=torch.uint8, device=dev) if record else None
+        bn = self.bn1
+        self._call("tic_bn_relu_maxpool_fwd", c0.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                   bn.num_batches_tracked.data_ptr(), m0.data_ptr(), r0.data_ptr(), self._bn_scratch(bn, dev).data_ptr(), h.data_ptr(),
+                   None if pidx is None else pidx.data_ptr(), B, H1, W1, 64, _EPS, _MOMENTUM, 1 if train else 0)
+        tape["stem"] = (col0, c0, m0, r0, H, W, H1, W1, pidx)
         Hc, Wc = Hp, Wp
         for blk in self._blocks():
             rec = {"in": h, "H": Hc, "W": Wc}
@@ -364,8 +366,8 @@ class TicResNet(nn.Module):
             elif not folded:
                 self._call("tic_add_bf16", d.data_ptr(), dident.data_ptr(), d.numel())
             dh = d
-        col0, c0, a0, m0, r0, H, W, H1, W1, pidx = tape["stem"]
-        da0 = torch.empty_like(a0)
+        col0, c0, m0, r0, H, W, H1, W1, pidx = tape["stem"]
+        da0 = torch.empty_like(c0)   # gradient of the (never stored) relu(bn1(c0)): from the pooled gradient and the argmax positions
         self._call("tic_maxpool3x3s2_bwd_idx", pidx.data_ptr(), dh.data_ptr(), da0.data_ptr(), B, H1, W1, 64)
         dc0 = self._bn_bwd(self.bn1, da0, None, c0, m0, r0, c0.shape[0], relu_from_x=True)
         self._conv_bwd(self.conv1, dc0, col0, B, H, W, need_dx=False)

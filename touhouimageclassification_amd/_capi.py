@@ -88,6 +88,7 @@ SIGNATURES = {
     "tic_batchnorm_bwd_relu": ([P, P, P, P, P, P, P, P, P, P, L, I, P], I),
     "tic_maxpool3x3s2_fwd": ([P, P, I, I, I, I, P], I),
     "tic_maxpool3x3s2_bwd": ([P, P, P, P, I, I, I, I, P], I),
+    "tic_bn_relu_maxpool_fwd": ([P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P], I),
     "tic_maxpool3x3s2_fwd_idx": ([P, P, P, I, I, I, I, P], I),
     "tic_maxpool3x3s2_bwd_idx": ([P, P, P, I, I, I, I, P], I),
     "tic_avgpool_fwd": ([P, P, I, I, I, P], I),

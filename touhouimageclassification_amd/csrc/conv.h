@@ -444,10 +444,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const bf16_t* __restr
     }
     for (long i = first; i < total; i += step) {
         const long off = (i / cpr) * C + c0;
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + off);
         const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + off);
         bf16x8 yv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         if (y) yv = *reinterpret_cast<const bf16x8*>(y + off);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + off);
         float o[8], z[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -595,6 +595,58 @@ __global__ void __launch_bounds__(256) maxpool_fwd_idx_kernel(const bf16_t* __re
         const long o = (((long)b * Ho + oy) * Wo + ox) * C + c0;
         *reinterpret_cast<u32x4*>(y + o) = u32x4{pack2bf(mx[0], mx[1]), pack2bf(mx[2], mx[3]), pack2bf(mx[4], mx[5]), pack2bf(mx[6], mx[7])};
         *reinterpret_cast<u32x2*>(idx + o) = u32x2{k8[0] | (k8[1] << 8) | (k8[2] << 16) | (k8[3] << 24), k8[4] | (k8[5] << 8) | (k8[6] << 16) | (k8[7] << 24)};
+    }
+}
+// The stem's bn1 -> relu -> maxpool in one pass: y = maxpool3x3/2(relu(bn(x))) with the argmax position, relu(bn(x)) rounded to bf16 per
+// element exactly as bn_apply_kernel stores it but never stored (411 MB written + read again at B = 256)
+__global__ void __launch_bounds__(256) bn_relu_maxpool_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                   unsigned char* idx, int B, int H, int W, int C, int Ho, int Wo) {
+    const int cpr = C / 8;
+    const long total = (long)B * Ho * Wo * cpr;
+    const long first = (long)TIC_BID_X * 256 + TIC_TID, step = (long)TIC_NBLK_X * 256;   // step % cpr == 0: one channel chunk per thread
+    const int c0 = (int)(first % cpr) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = rstd[c0 + j] * gamma[c0 + j];
+        sh[j] = beta[c0 + j] - mean[c0 + j] * sc[j];
+    }
+    for (long i = first; i < total; i += step) {
+        long t = i / cpr;
+        const int ox = (int)(t % Wo);
+        t /= Wo;
+        const int oy = (int)(t % Ho), b = (int)(t / Ho);
+        float mx[8];
+        uint32_t k8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            mx[j] = -__builtin_huge_valf();
+            k8[j] = 0;
+        }
+        bool firstpos = true;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((long)b * H + iy) * W + ix) * C + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float f = bf2f((bf16_t)v[j]) * sc[j] + sh[j];
+                    f = bfround(f < 0.f ? 0.f : f);
+                    if (firstpos || f > mx[j]) {
+                        mx[j] = f;
+                        k8[j] = (uint32_t)(ky * 3 + kx);
+                    }
+                }
+                firstpos = false;
+            }
+        }
+        const long o = (((long)b * Ho + oy) * Wo + ox) * C + c0;
+        *reinterpret_cast<u32x4*>(y + o) = u32x4{pack2bf(mx[0], mx[1]), pack2bf(mx[2], mx[3]), pack2bf(mx[4], mx[5]), pack2bf(mx[6], mx[7])};
+        if (idx) *reinterpret_cast<u32x2*>(idx + o) = u32x2{k8[0] | (k8[1] << 8) | (k8[2] << 16) | (k8[3] << 24), k8[4] | (k8[5] << 8) | (k8[6] << 16) | (k8[7] << 24)};
     }
 }
 __global__ void __launch_bounds__(256) maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,

@@ -939,6 +939,24 @@ extern "C" int tic_batchnorm_bwd_relu(const void* dy, const void* x, const float
     TIC_REQUIRE(beta, "batchnorm_bwd_relu: null beta");
     return batchnorm_bwd_impl(dy, nullptr, x, mean, rstd, gamma, beta, scratch2c, dx, nullptr, 0, dgamma, dbeta, M, C, stream);
 }
+// The ResNet stem's tail in one piece (TIC/ResNet/model.py:150-152: bn1 -> relu -> maxpool): y_pool = maxpool3x3/2(relu(bn(x))) and the
+// argmax positions, WITHOUT storing relu(bn(x)).  Bit-identical to tic_batchnorm_fwd(relu) + tic_maxpool3x3s2_fwd_idx; the backward is
+// tic_maxpool3x3s2_bwd_idx + tic_batchnorm_bwd_relu (fusing those too was measured slower: both BatchNorm passes would repeat the
+// window gather, 462 + 343 us against 207 + 160 + 240).  scratch2c as in tic_batchnorm_fwd (zero on entry, left zero).
+extern "C" int tic_bn_relu_maxpool_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
+                                       float* mean, float* rstd, float* scratch2c, void* y_pool, void* idx_u8_or_null, int B, int H, int W, int C, float eps,
+                                       float momentum, int train, tic_stream_t stream) {
+    TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && scratch2c && y_pool, "bn_relu_maxpool_fwd: null pointer");
+    TIC_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "bn_relu_maxpool_fwd: need C/8 to divide 256");
+    const long M = (long)B * H * W;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    if (train) TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, bn_rows(M, C)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, scratch2c, M, C);
+    TIC_LAUNCH(bn_finalize_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, mean, rstd, running_mean, running_var, (long long*)num_batches, M, C, eps,
+               momentum, train);
+    TIC_LAUNCH(bn_relu_maxpool_fwd_kernel, ew_grid((long)B * Ho * Wo * (C / 8)), 256, 0, stream, (const bf16_t*)x, mean, rstd, gamma, beta, (bf16_t*)y_pool,
+               (unsigned char*)idx_u8_or_null, B, H, W, C, Ho, Wo);
+    return tic_after_launch("bn_relu_maxpool_fwd");
+}
 extern "C" int tic_maxpool3x3s2_fwd(const void* x, void* y, int B, int H, int W, int C, tic_stream_t stream) {
     TIC_REQUIRE(x && y && C % 8 == 0, "maxpool_fwd: need C %% 8 == 0");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
