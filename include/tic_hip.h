@@ -37,6 +37,7 @@ const char* tic_last_error_string(void);
  *   "gemm_tile"  0 (auto) | 128 | 256       which NT / TN tile family to use
  *   "tn_streamk" 1 (256 shares) | 0 | n     stream-K split of the grouped dW launch
  *   "tn_phase"   1 | 0                      phase-aligned vs flat stream-K split
+ *   "tn_slab"    1 | 0                      few-tile weight gradients through the tic_gemm_tn_scratch slab vs stream-K atomics
  *   "tn_parts"   -1 (auto) | 0 | 2..8       tile counts without a phase-aligned split (ViT-B: 108): every tile in n equal row parts (auto: 256 / tiles) | flat stream-K
  *   "tn_mfma"    0 (auto) | 16 | 32         MFMA shape of the grouped dW stream-K launch (16x16x32 for long reductions, else 32x32x16)
  *   "tn_block"   -1 (auto) | 0 | n          tile-walk block width of that launch (XCD-sized blocks | row-major | fixed)
@@ -192,6 +193,11 @@ int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, i
 int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* dw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                          int stride, int pad, tic_stream_t stream);
 int tic_conv_weight_grad(const float* dw_ohwi, float* grad_oihw, int Co, int Ci, int kh, int kw, tic_stream_t stream); /* grad += */
+/* optional scratch for few-tile weight gradients (tic_gemm_tn_bf16 with N, K multiples of 256, M >= 8192, <= 64 tiles: the 1 x 1
+ * convolutions of a deep ResNet stage): every tile is cut into row parts that STORE their partial tiles into the scratch and one more
+ * launch adds them to C, instead of stream-K shares that each add a whole tile with fp32 atomics.  Caller-owned, per host thread, 64 MiB
+ * covers every case; pass NULL to unregister.  Without it nothing changes. */
+int tic_gemm_tn_scratch(void* scratch, size_t bytes);
 /* tic_conv_weight_pack / tic_conv_weight_grad for a whole network in one launch each: `descs` points to n entries in DEVICE memory
  * (the caller builds the table once; entries are consumed by blockIdx.y).  Same arithmetic per entry as the single calls. */
 typedef struct {

@@ -551,3 +551,24 @@ def check_refresh_weights(model):
             w = flat[lay.layer0 + l * lay.layer_stride + off:][: R * C].view(R, C)
             wt = eng.wT16[l * lay.t_layer_stride + toff:][: R * C].view(C, R)
             assert torch.equal(wt, w.to(torch.bfloat16).t().contiguous()), (l, R, C)
+
+
+def check_gemm_tn_slab(env, M, N, K, slab_mb=64):
+    """few-tile weight gradient through a registered slab scratch (row parts STORE their partial tiles, one more launch adds them up)
+    against the stream-K atomics form and fp32 math; accumulate semantics (C +=) in both"""
+    rnd, call, dev = env.rnd, env.call, env.dev
+    A, B = bf(rnd(M, N)), bf(rnd(M, K))
+    C0 = rnd(N, K)
+    ref = C0 + A.float().t() @ B.float()
+    Ca, Cs = C0.clone(), C0.clone()
+    call("tic_gemm_tn_bf16", ptr(A), ptr(B), ptr(Ca), M, N, K, None)
+    scratch = torch.full((slab_mb << 20,), 0x7f, dtype=torch.uint8, device=dev)   # garbage on purpose: every part must overwrite what the reduce reads
+    env._call("tic_gemm_tn_scratch", ptr(scratch), scratch.numel())
+    try:
+        call("tic_gemm_tn_bf16", ptr(A), ptr(B), ptr(Cs), M, N, K, None)
+        call("tic_gemm_tn_bf16", ptr(A), ptr(B), ptr(Cs), M, N, K, None)   # accumulates
+    finally:
+        env._call("tic_gemm_tn_scratch", None, 0)
+    tol = dict(atol=2e-3 * max(1.0, (M / 200) ** 0.5), rtol=1e-3)
+    torch.testing.assert_close(Ca, ref, **tol)
+    torch.testing.assert_close(Cs, ref + (ref - C0), atol=2 * tol["atol"], rtol=1e-3)

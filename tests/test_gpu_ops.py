@@ -128,3 +128,9 @@ def test_splitk_nt_kernel(env, M, N, K, split):
     """the split-K form at the shapes it is for (ViT-L, 8 .. 32 images per GPU: 28 / 52 / 100 tiles) -- and one it must refuse
     (200 tiles x 2 > 256 workgroups: the launch stays unsplit and still has to be right)"""
     kc.check_splitk_nt(env, M, N, K, split)
+
+
+@pytest.mark.parametrize("M,N,K", [(40960, 1024, 256), (50176, 256, 1024), (12544, 2048, 512), (12544, 512, 2048), (8200, 256, 256), (200704, 512, 256)])
+def test_gemm_tn_parts_slab_route(env, M, N, K):
+    """ResNet 1x1 weight-gradient shapes (4 .. 16 tiles over 12 544 .. 200 704 rows): row parts stored to the slab + one reduce launch"""
+    kc.check_gemm_tn_slab(env, M, N, K)

@@ -140,3 +140,8 @@ def test_persistent_nt_kernel_is_bit_identical(env, M, N, K, pgrid):
 def test_splitk_nt_kernel(env, M, N, K, split):
     """2 tiles x 2 parts (4 K tiles each) / 2 tiles x 4 parts: producers run first in the simulator's block order"""
     kc.check_splitk_nt(env, M, N, K, split)
+
+
+def test_gemm_tn_parts_slab_route(env):
+    """2 tiles x 129 steps (ragged last step): 32 row parts per tile store into the slab, one reduce launch adds them to C"""
+    kc.check_gemm_tn_slab(env, 8200, 256, 512, slab_mb=24)

@@ -23,6 +23,7 @@ from ..engine import _HipBackend
 _CFG = {"resnet18": ("basic", [2, 2, 2, 2]), "resnet34": ("basic", [3, 4, 6, 3]), "resnet50": ("bottleneck", [3, 4, 6, 3]),
         "resnet101": ("bottleneck", [3, 4, 23, 3]), "resnet152": ("bottleneck", [3, 8, 36, 3])}
 _EPS, _MOMENTUM = 1e-5, 0.1
+_TN_SLAB_BYTES = 64 << 20   # scratch of the few-tile weight gradients: parts x Cout x Cin x 4 B = 64 MiB when parts x tiles = 256
 
 
 class _Conv(nn.Module):
@@ -235,6 +236,11 @@ class TicResNet(nn.Module):
                 c.__dict__["_dw_view"] = dws[off:off + c.cout * c.kp]
                 off += c.cout * c.kp
         dws.zero_()
+        # slab scratch of the few-tile weight gradients (row parts stored + one reduce launch instead of stream-K atomics)
+        slab = self.__dict__.get("_tn_slab")
+        if slab is None or slab.device != dev:
+            slab = self.__dict__["_tn_slab"] = torch.empty(_TN_SLAB_BYTES, dtype=torch.uint8, device=dev)
+        self.backend.call("tic_gemm_tn_scratch", slab.data_ptr(), slab.numel())
 
     def _conv_bwd(self, conv: _Conv, dy, col, B, H, W, need_dx: bool, dx_accumulate_into=None):
         """dy [M,Cout]; returns dx [B*H*W, Cin] bf16 (or None) and accumulates the weight gradient"""
@@ -332,6 +338,12 @@ class TicResNet(nn.Module):
         return logits, (tape if record else None)
 
     def _backward_impl(self, dlogits: torch.Tensor, tape):
+        try:
+            self._backward_body(dlogits, tape)
+        finally:   # the slab scratch registered by _begin_backward must not outlive this call (it is a raw pointer in the library)
+            self.backend.call("tic_gemm_tn_scratch", None, 0)
+
+    def _backward_body(self, dlogits: torch.Tensor, tape):
         B = tape["B"]
         z, Hc, Wc, feat = tape["head"]
         dev = dlogits.device

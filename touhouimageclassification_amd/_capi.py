@@ -49,6 +49,7 @@ SIGNATURES = {
     "tic_kernel_timer_enable": ([I], I),
     "tic_kernel_timer_read": ([P, P], I),
     "tic_gemm_nt_scratch": ([P, SZ], I),
+    "tic_gemm_tn_scratch": ([P, SZ], I),
     "tic_gemm_nt_bf16": ([P, P, I, I, I, I, P, P, P, P, P, P, P, I, P], I),
     "tic_gemm_nt_bf16_ex": ([P, P, I, I, I, I, P, P, P, P, P, P, P, I, P, P], I),
     "tic_layernorm_bwd_ex": ([P, P, L, P, P, P, P, P, P, P, P, P, I, I, P], I),

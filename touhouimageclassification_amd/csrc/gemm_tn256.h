@@ -60,10 +60,11 @@ TIC_DEV void tn_tile_lookup(const GemmTnGroupParams& gp, int tile, const bf16_t*
 }
 
 // One 256x256 output tile (origin n0, k0 of problem A/B/C) over the M steps [step0, step1) of 64 rows.
-// ATOMIC = false: the workgroup owns the whole reduction, C += acc with plain read-modify-write;
-// ATOMIC = true : partial reduction (stream-K share), C += acc with fp32 atomics (two 128-B row segments / instruction).
+// ATOMIC = 0: the workgroup owns the whole reduction, C += acc with plain read-modify-write;
+// ATOMIC = 1: partial reduction (stream-K share), C += acc with fp32 atomics (two 128-B row segments / instruction);
+// ATOMIC = 2: partial reduction STORED (C here is one slice of a slab that tn_slab_reduce_kernel adds up afterwards).
 // DBG (measurement only, see gemm256.h): bit 0 = no LDS-DMA, bit 1 = no fragment reads, bit 2 = no MFMA.
-template <bool ATOMIC, int DBG = 0>
+template <int ATOMIC, int DBG = 0>
 TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, int N, int K, int M, int n0, int k0, int step0, int step1) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wr = w >> 2, wc = w & 3;
@@ -292,7 +293,8 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
                 for (int r = 0; r < 16; ++r) {
                     const int n = n0 + i * 128 + wr * 64 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
                     float* dst = Cp + (size_t)n * K + kk;
-                    if (ATOMIC) atomic_addf(dst, acc[i][j][nt][r]);
+                    if (ATOMIC == 1) atomic_addf(dst, acc[i][j][nt][r]);
+                    else if (ATOMIC == 2) *dst = acc[i][j][nt][r];
                     else *dst = *dst + acc[i][j][nt][r];
                 }
             }
@@ -308,7 +310,7 @@ TIC_DEV void tn256_tile_segment(const bf16_t* Ap, const bf16_t* Bp, float* Cp, i
 //   swizzle     one read instruction covers rows {8 g + q : g in a pair, q = 0..3} = 8 rows x 32 B; the 256-B bank row has 8
 //               such slots, so the 16-B chunk index is XORed with (q << 2) ^ ((g & 1) << 1) on both sides (DMA source and read).
 //   D layout    col = l & 15 -> k (16 contiguous fp32 = 64 B per row and instruction), row = 4 (l >> 4) + reg -> n.
-template <bool ATOMIC>
+template <int ATOMIC>
 TIC_DEV void tn256_tile_segment16(const bf16_t* Ap, const bf16_t* Bp, float* Cp, int N, int K, int M, int n0, int k0, int step0, int step1) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wr = w >> 2, wc = w & 3;
@@ -522,7 +524,8 @@ TIC_DEV void tn256_tile_segment16(const bf16_t* Ap, const bf16_t* Bp, float* Cp,
                     for (int r = 0; r < 4; ++r) {
                         const int n = n0 + i * 128 + wr * 64 + mt * 16 + 4 * (l >> 4) + r;
                         float* dst = Cp + (size_t)n * K + kk;
-                        if (ATOMIC) atomic_addf(dst, acc[i][j][mt][nt][r]);
+                        if (ATOMIC == 1) atomic_addf(dst, acc[i][j][mt][nt][r]);
+                        else if (ATOMIC == 2) *dst = acc[i][j][mt][nt][r];
                         else *dst = *dst + acc[i][j][mt][nt][r];
                     }
                 }
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
     float* Cp;
     int N, K, n0, k0;
     tn_tile_lookup(gp, wg, Ap, Bp, Cp, N, K, n0, k0);
-    tn256_tile_segment<false, DBG>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, (gp.M + 63) / 64);
+    tn256_tile_segment<0, DBG>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, (gp.M + 63) / 64);
 }
 
 // Stream-K forms: every CU gets an equal share of the (tile, M step) work instead of 192 busy + 64 idle CUs.  A share is
@@ -602,7 +605,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
         float* Cp; \
         int N, K, n0, k0; \
         tn_tile_lookup(gp, tile0 + it, Ap, Bp, Cp, N, K, n0, k0); \
-        SEG<true>(Ap, Bp, Cp, N, K, gp.M, n0, k0, it == 0 ? a0 : a_rest, it == nseg - 1 ? b_last : nsteps); \
+        SEG<1>(Ap, Bp, Cp, N, K, gp.M, n0, k0, it == 0 ? a0 : a_rest, it == nseg - 1 ? b_last : nsteps); \
     }
 
 // the grouped launch of one transformer block (the step's dominant kernel: bench.py times exactly these launches) ...
@@ -617,4 +620,28 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_mfma32_kernel(GemmT
 // ResNet 1x1 convolutions), so that per-kernel profiler averages of the block launch stay clean
 __global__ void __launch_bounds__(512, 2) gemm_tn256_streamk_single_kernel(GemmTnGroupParams gp, int nsteps, int s_main, int tpx, int tail_each) {
     TN256_STREAMK_BODY(tn256_tile_segment16)
+}
+
+// Few tiles, long reduction (the 1x1-convolution weight gradients of a deep ResNet stage: C_out x C_in = 1024 x 256 -> 4 tiles over
+// 40 960 rows).  As stream-K shares every workgroup ends by adding a whole 256 KiB tile to C with fp32 atomics, and one CU issues those
+// at ~5 GB/s: 51 us of an 88 us launch, with nothing else resident on the CU to hide it.  Here every tile is cut into P equal row
+// parts (P x tiles <= 256), part p of every tile STORES its partial tile into slice p of a caller-owned slab [P][N][K] (plain stores:
+// 10 us per CU) and tn_slab_reduce_kernel adds the slices to C.  Workgroup -> (tile = bid % tiles, part = bid / tiles): the workgroups
+// of one part sweep the same rows of both operands at the same time.
+__global__ void __launch_bounds__(512, 2) gemm_tn256_parts_slab_kernel(GemmTnGroupParams gp, float* slab, int nsteps, int per) {
+    const int tile = TIC_BID_X % gp.total_tiles, part = TIC_BID_X / gp.total_tiles;
+    const bf16_t *Ap, *Bp;
+    float* Cp;
+    int N, K, n0, k0;
+    tn_tile_lookup(gp, tile, Ap, Bp, Cp, N, K, n0, k0);
+    const int a = part * per, b = (a + per < nsteps) ? a + per : nsteps;   // the host launches only parts with a < nsteps
+    tn256_tile_segment16<2>(Ap, Bp, slab + (size_t)part * N * K, N, K, gp.M, n0, k0, a, b);
+}
+// C[i] += sum over the `parts` slices of slab[part][i]; n4 = N*K / 4
+__global__ void __launch_bounds__(256) tn_slab_reduce_kernel(float* __restrict__ C, const float* __restrict__ slab, int parts, long n4) {
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < n4; i += (long)TIC_NBLK_X * 256) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(C + i * 4);
+        for (int p = 0; p < parts; ++p) a += *reinterpret_cast<const f32x4*>(slab + ((long)p * n4 + i) * 4);
+        *reinterpret_cast<f32x4*>(C + i * 4) = a;
+    }
 }

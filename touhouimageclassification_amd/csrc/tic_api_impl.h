@@ -71,6 +71,7 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
     return TIC_OK;
 }
 #endif
+static int g_opt_tn_slab = 1;             // few-tile weight gradients: row parts stored to the tic_gemm_tn_scratch slab + one reduce launch (1) | stream-K atomics (0)
 static int g_opt_tn_split_wgs = 1024;    // split-M weight-gradient kernels (128x128 tiles): workgroups aimed at (every split adds its tile to C with fp32 atomics)
 static int g_opt_tn_parts = -1;           // grouped dW without a phase-aligned split: -1 auto (256 / tiles equal row parts per tile), 0 never (flat stream-K), n forced
 static int g_opt_tn_streamk_min_steps = 128;   // grouped dW: fewest 64-row steps for which the stream-K split is chosen
@@ -109,6 +110,10 @@ extern "C" int tic_set_option(const char* name, int value) {
     }
     if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
         g_opt_nt = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "tn_slab") && (value == 0 || value == 1)) {
+        g_opt_tn_slab = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "tn_split_wgs") && value >= 64 && value <= 8192) {
@@ -207,6 +212,16 @@ static unsigned g_nt_epoch = 0;
 extern "C" int tic_gemm_nt_scratch(void* scratch, size_t bytes) {
     TIC_REQUIRE(!scratch || (bytes >= TIC_NT_SLAB_BYTES + 4096 && TIC_ALIGNED16(scratch)), "gemm_nt_scratch: need %zu bytes, 16-byte aligned", TIC_NT_SLAB_BYTES + 4096);
     g_nt_scratch = (char*)scratch;
+    return TIC_OK;
+}
+// Scratch for few-tile weight gradients (tic_gemm_tn_bf16 on its 256x256 route, gemm_tn256_parts_slab_kernel): caller-owned, per host
+// thread.  Without it (or when parts x N x K x 4 bytes do not fit) those launches stay stream-K shares with fp32 atomics.
+static thread_local float* g_tn_slab = nullptr;
+static thread_local size_t g_tn_slab_bytes = 0;
+extern "C" int tic_gemm_tn_scratch(void* scratch, size_t bytes) {
+    TIC_REQUIRE(!scratch || TIC_ALIGNED16(scratch), "gemm_tn_scratch: need 16-byte alignment");
+    g_tn_slab = (float*)scratch;
+    g_tn_slab_bytes = scratch ? bytes : 0;
     return TIC_OK;
 }
 extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, int K, int epilogue, const float* bias,
@@ -475,6 +490,21 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
                 if (P >= 2 && 8 * txm * P <= 320 && (forced || (nsteps / P >= 64 && (long)P * t >= 192))) {
                     s_main = -P;
                     grid_wg = 8 * txm * P;
+                }
+            }
+            // single problem of few tiles with a slab registered: equal row parts that STORE their partial tiles + one reduce launch
+            if (force256 && nprob == 1 && g_opt_tn_slab && g_tn_slab && t <= 64 && t >= 1) {
+                int P = (int)(256 / t);
+                if (P > nsteps / 4) P = nsteps / 4;   // at least 4 steps per part
+                const size_t nk = (size_t)N[0] * K[0];
+                if (P >= 2 && (size_t)P * nk * 4 <= g_tn_slab_bytes) {
+                    const int per = (nsteps + P - 1) / P, parts = (nsteps + per - 1) / per;   // every launched part is non-empty
+                    TIC_RT_MAX_LDS(gemm_tn256_parts_slab_kernel, G256_LDS_BYTES);
+                    TIC_LAUNCH(gemm_tn256_parts_slab_kernel, t * parts, 512, G256_LDS_BYTES, stream, gp, g_tn_slab, nsteps, per);
+                    long blocks = ((long)(nk / 4) + 255) / 256;
+                    if (blocks > 2048) blocks = 2048;
+                    TIC_LAUNCH(tn_slab_reduce_kernel, (int)blocks, 256, 0, stream, C[0], (const float*)g_tn_slab, parts, (long)(nk / 4));
+                    return tic_after_launch("gemm_tn(parts + slab)");
                 }
             }
             if (force256) {   // single-problem route: same code, own kernel name, not part of the live timer
