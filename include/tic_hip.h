@@ -44,7 +44,8 @@ const char* tic_last_error_string(void);
  *   "gemm_big_tiles" 128                    fewest 256x256 tiles for which the 256x256 NT kernel is chosen (below: the 128x128 kernel)
  *   "tn_streamk_min_steps" 128              fewest 64-row reduction steps for which the grouped dW launch is stream-K split (below: one workgroup per tile)
  *   "ln_bwd_rows" 2                         LayerNorm backward: fewest rows per wave
- *   "gemm_split" -1 (auto: only at exactly gemm_big_tiles tiles) | 0 | 2 | 4   split-K form of the 256x256 NT kernel (needs tic_gemm_nt_scratch)
+ *   "gemm_split" -1 (auto) | 0 | 2 | 4       split-K forms of the NT kernels (need tic_gemm_nt_scratch); auto: the 128x128 kernel in two parts where
+ *                                            2 x tiles fit 512 workgroups and a part keeps >= 16 K tiles, the 256x256 kernel only at exactly gemm_big_tiles tiles
  *   "gemm_persist" 0 | 1                    persistent form of the 256x256 NT kernel (measured slower: off)
  *   "gemm_pgrid" 256                        its grid (tests)
  *   "stream_nt"  bit mask, default 13       non-temporal cache policy: 1 LayerNorm, 2 AdamW, 4 GEMM epilogue stores, 8 epilogue operand loads

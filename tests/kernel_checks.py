@@ -497,7 +497,7 @@ def check_persistent_nt_matches(env, M, N, K, pgrid):
         env._call("tic_set_option", b"gemm_persist", 0)
 
 
-def check_splitk_nt(env, M, N, K, split):
+def check_splitk_nt(env, M, N, K, split, tile=256):
     """the split-K form of the 256x256 NT kernel (2 or 4 workgroups per tile, fp32 partial accumulators handed over through a
     caller-owned scratch, flags that count launches) against the unsplit kernel and fp32 math: same single rounding to bf16, only the
     fp32 summation order differs"""
@@ -516,7 +516,7 @@ def check_splitk_nt(env, M, N, K, split):
              ptr(resid) if epi == 2 else None, None, None, 0, ptr(cs) if epi == 0 else None, None)
         return (o1 if epi == 0 else of), cs
 
-    env._call("tic_set_option", b"gemm_tile", 256)
+    env._call("tic_set_option", b"gemm_tile", tile)   # 256: gemm256.h's split-K form; 128: gemm.h's (any epilogue; 0 and 2 are checked)
     env._call("tic_gemm_nt_scratch", ptr(scratch), scratch.numel())
     try:
         ref32 = A.float() @ B.float().t() + bias

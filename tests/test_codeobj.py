@@ -53,5 +53,9 @@ def test_register_budgets(kernels):
     for k in get("void attn_fwd_kernel<"):            # 4 or 8 waves, launch bound 2 waves per SIMD
         assert k["vgpr_count"] <= 256, k
     for prefix in ("void gemm_nt_kernel<", "void gemm_tn_kernel<"):   # 256-thread 128^2 tiles: 4 waves/SIMD wanted
-        for k in get(prefix):
-            assert k["vgpr_count"] <= 128, (prefix, k)
+        for n, k in kernels.items():
+            if n.startswith(prefix):
+                # (the split-K forms <EPI, false, 1> batch the 16 slab loads of the hand-off: LDS allows two workgroups per CU = 2 waves
+                # per SIMD anyway, so they may use the 256-register half)
+                limit = 256 if n.rstrip().endswith(", false, 1>(GemmNtParams)") else 128
+                assert k["vgpr_count"] <= limit, (prefix, n, k)

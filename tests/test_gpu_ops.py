@@ -134,3 +134,9 @@ def test_splitk_nt_kernel(env, M, N, K, split):
 def test_gemm_tn_parts_slab_route(env, M, N, K):
     """ResNet 1x1 weight-gradient shapes (4 .. 16 tiles over 12 544 .. 200 704 rows): row parts stored to the slab + one reduce launch"""
     kc.check_gemm_tn_slab(env, M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(1576, 1024, 4096, 2), (1576, 1024, 4096, 4), (3152, 1024, 3072, 2), (1576, 1024, 1024, 2)])
+def test_splitk_nt_kernel_128(env, M, N, K, split):
+    """the 128x128 kernel's split-K form at ViT-L's 8 / 16-image shapes (104 / 200 tiles)"""
+    kc.check_splitk_nt(env, M, N, K, split, tile=128)

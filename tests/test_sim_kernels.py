@@ -145,3 +145,9 @@ def test_splitk_nt_kernel(env, M, N, K, split):
 def test_gemm_tn_parts_slab_route(env):
     """2 tiles x 129 steps (ragged last step): 32 row parts per tile store into the slab, one reduce launch adds them to C"""
     kc.check_gemm_tn_slab(env, 8200, 256, 512, slab_mb=24)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(200, 256, 512, 2), (130, 128, 1024, 4)])
+def test_splitk_nt_kernel_128(env, M, N, K, split):
+    """the 128x128 kernel's split-K form: 4 tiles x 2 parts (4 K tiles each) / 2 tiles x 4 parts"""
+    kc.check_splitk_nt(env, M, N, K, split, tile=128)

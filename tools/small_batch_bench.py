@@ -53,7 +53,7 @@ def main():
                 call("tic_gemm_nt_bf16", a.data_ptr(), w.data_ptr(), M, n, k, epi, None if epi == 3 else bias.data_ptr(), o1.data_ptr(), o2.data_ptr(),
                      None if of is None else of.data_ptr(), None if resid is None else resid.data_ptr(), None if aux is None else aux.data_ptr(), None, 0, current_stream())
             row = []
-            for label, tile, sp in (("128", 128, 0), ("256", 256, 0), ("auto", 0, -1)):
+            for label, tile, sp in (("128", 128, 0), ("128/2", 128, 2), ("128/4", 128, 4), ("256", 256, 0), ("auto", 0, -1)):
                 call("tic_set_option", b"gemm_tile", tile)
                 call("tic_set_option", b"gemm_split", sp)
                 us = time_us(run)

@@ -189,13 +189,20 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
 #define GEMM_STAGE_BYTES 32768   // A tile 16 KiB + B tile 16 KiB
 #define GEMM_LDS_BYTES (2 * GEMM_STAGE_BYTES)
 
-template <int EPI, bool CONV = false>
+// SPLITK = 1 (few tiles, long reduction: ViT-L at 8-16 images per GPU, N = 1024, K >= 3072 -- 104 / 200 tiles on 512 workgroup slots, each
+// a 64-tile K loop whose LATENCY is the launch time): p.split = 2 or 4 workgroups per tile, block b -> (tile b % tiles, part b / tiles).
+// Parts before the last store their fp32 accumulators (64 KiB, coalesced float4 per lane) to p.slab and publish p.flags[tile * 4 + part]
+// = p.epoch; the last part (highest block ids: its producers are always dispatched first) waits, adds the slabs in part order and
+// runs the ordinary epilogue.  Same hand-off as gemm256.h's split-K form.
+template <int EPI, bool CONV = false, int SPLITK = 0>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wm = w >> 1, wn = w & 1;
     const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;   // B rows >= N read 0
+    const int ntiles = tiles_m * tiles_n, nparts = SPLITK ? p.split : 1;
+    const int part = SPLITK ? TIC_BID_X / ntiles : 0, tile_id = SPLITK ? TIC_BID_X - part * ntiles : TIC_BID_X;
     int tm, tn;
-    tile_coords(TIC_BID_X, tiles_m * tiles_n, tiles_m, tiles_n, tm, tn);
+    tile_coords(tile_id, ntiles, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
 
     const size_t a_bytes = CONV ? (size_t)(p.M / (p.cg.Ho * p.cg.Wo)) * p.cg.H * p.cg.W * p.cg.Cin * 2 : (size_t)p.M * p.K * 2;
@@ -258,18 +265,18 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + j * 16 + 4 * (l >> 4);
-        const f32x4 b4 = (p.bias && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 b4 = (p.bias && col < p.N && part == nparts - 1) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = b4;
     }
 
-    const int nk = p.K / GEMM_BK;
-    stage(0, 0);
+    const int nk = (p.K / GEMM_BK) / nparts, kt0 = part * nk;   // K tiles of THIS workgroup
+    stage(0, kt0);
     wait_vmcnt0();
     block_sync();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        if (kt + 1 < nk) stage(cur ^ 1, kt0 + kt + 1);
         const uint32_t sb = (uint32_t)cur * GEMM_STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -289,6 +296,28 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
         block_sync();
     }
 
+    if (SPLITK) {   // thread t owns float4 slots t, 256 + t, ... of a 64-KiB slab
+        if (part < nparts - 1) {
+            float* dst = p.slab + ((size_t)(tile_id * (nparts - 1) + part) * 16 * 256 + tid) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (size_t)(i * 4 + j) * 256 * 4) = acc[i][j];
+            wait_vmcnt0();
+            block_sync();
+            if (tid == 0) flag_publish(p.flags + tile_id * 4 + part, p.epoch);
+            return;
+        }
+        for (int q = 0; q < nparts - 1; ++q) {
+            if (tid == 0) flag_wait(p.flags + tile_id * 4 + q, p.epoch);
+            block_sync();
+            const float* src = p.slab + ((size_t)(tile_id * (nparts - 1) + q) * 16 * 256 + tid) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(src + (size_t)(i * 4 + j) * 256 * 4);
+        }
+    }
     // ---- epilogue: lane holds rows m = ..+(l&15), 4 consecutive n = ..+4(l>>4) ------------------------
     gemm_epilogue<EPI, 4, 4>(
         p, [&](int r) { return m0 + wm * 64 + r * 16 + (l & 15); }, [&](int g) { return n0 + wn * 64 + g * 16 + 4 * (l >> 4); },

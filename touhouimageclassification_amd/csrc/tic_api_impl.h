@@ -289,6 +289,19 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
             break;
         }
     }
+    // the same for the 128x128 kernel (two workgroups per CU = 512 slots): 2 or 4 parts while every part keeps >= 16 K tiles and the
+    // launch still fits the slots; any epilogue (the consumer runs the ordinary one on the summed accumulators)
+    if (!big && g_nt_scratch && g_opt_gemm_split != 0 && g_opt_gemm_split != 1 && epilogue != TIC_EPI_PATCH && N % 128 == 0) {
+        const int nk_ = K / 64;
+        for (int sp = 4; sp >= 2; sp >>= 1) {
+            if (g_opt_gemm_split > 0 && sp != g_opt_gemm_split) continue;
+            if (nk_ % sp != 0 || (long)grid * sp > 512 || grid > 256 || (size_t)grid * (sp - 1) * 65536 > TIC_NT_SLAB_BYTES) continue;
+            // auto: two parts only (four measured slower at every shape: 38.0 vs 34.0, 42.7 vs 33.8 us), each >= 16 K tiles
+            if (g_opt_gemm_split < 0 && (sp != 2 || nk_ / sp < 16)) continue;
+            split = sp;
+            break;
+        }
+    }
     p.split = split;
     p.slab = (float*)g_nt_scratch;
     p.flags = (unsigned*)(g_nt_scratch ? g_nt_scratch + TIC_NT_SLAB_BYTES : nullptr);
@@ -296,7 +309,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     if (split > 1 && p.epoch == 0) p.epoch = ++g_nt_epoch;   // 0 is what freshly zeroed flags hold
 #define TIC_GEMM_NT_LAUNCH_S(E)                                                                      \
     do {                                                                                             \
-        if (split > 1) {                                                                             \
+        if (split > 1 && big) {                                                                      \
             TIC_RT_MAX_LDS((gemm_nt256_kernel<E, 0, 1>), G256_NT_LDS_BYTES);                         \
             TIC_LAUNCH((gemm_nt256_kernel<E, 0, 1>), grid * split, 512, G256_NT_LDS_BYTES, stream, p); \
         } else {                                                                                     \
@@ -319,6 +332,9 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         if (big) {                                                                                   \
             TIC_RT_MAX_LDS(gemm_nt256_kernel<E>, G256_NT_LDS_BYTES);                                 \
             TIC_LAUNCH(gemm_nt256_kernel<E>, grid, 512, G256_NT_LDS_BYTES, stream, p);               \
+        } else if (split > 1) {                                                                      \
+            TIC_RT_MAX_LDS((gemm_nt_kernel<E, false, 1>), GEMM_LDS_BYTES);                           \
+            TIC_LAUNCH((gemm_nt_kernel<E, false, 1>), grid * split, 256, GEMM_LDS_BYTES, stream, p); \
         } else {                                                                                     \
             TIC_RT_MAX_LDS(gemm_nt_kernel<E>, GEMM_LDS_BYTES);                                       \
             TIC_LAUNCH(gemm_nt_kernel<E>, grid, 256, GEMM_LDS_BYTES, stream, p);                     \
@@ -350,7 +366,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
             break;
         case TIC_EPI_RESID:
             TIC_REQUIRE(out_f32 && resid, "gemm_nt: EPI_RESID needs out_f32 and resid");
-            if (split > 1) {
+            if (split > 1 && big) {
                 TIC_RT_MAX_LDS((gemm_nt256_kernel<TIC_EPI_RESID, 0, 1>), G256_NT_LDS_BYTES);
                 TIC_LAUNCH((gemm_nt256_kernel<TIC_EPI_RESID, 0, 1>), grid * split, 512, G256_NT_LDS_BYTES, stream, p);
                 break;
