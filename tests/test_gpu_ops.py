@@ -21,7 +21,8 @@ def test_gemm_nt_bias_bf16(env, M, N, K):
     kc.check_gemm_nt_bias_bf16(env, M, N, K)
 
 
-@pytest.mark.parametrize("N,K,imgs,Pn", [(128, 128, 3, 50), (1024, 768, 16, 196), (4096, 1024, 7, 197)])
+@pytest.mark.parametrize("N,K,imgs,Pn", [(128, 128, 3, 50), (1024, 768, 16, 196), (4096, 1024, 7, 197),
+                                         (1024, 768, 44, 196), (3072, 1024, 13, 197)])   # the last two: 136 / 132 tiles -> the 256x256 kernel's epilogues
 def test_gemm_nt_epilogues(env, N, K, imgs, Pn):
     kc.check_gemm_nt_gelu_resid_dgelu_patch(env, N, K, imgs, Pn)
 
