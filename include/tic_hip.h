@@ -79,6 +79,7 @@ int tic_gemm_nt_scratch(void* scratch, size_t bytes);
 #define TIC_EPI_GELU_DG 5 /* u = bf16(acc + bias); out = bf16(gelu'(u)); out2 = bf16(gelu_erf(u))   fc1 + GELU, derivative saved
                              instead of the pre-activation: the erf / exp work is shared and the backward becomes one multiply */
 #define TIC_EPI_MULAUX 6  /* out = bf16(bf16(acc) * aux)                               backward through GELU with aux = gelu'(u) */
+#define TIC_EPI_GELU_ONLY 8 /* out2 = bf16(gelu_erf(bf16(acc + bias))), nothing else stored     fc1 + GELU in a forward that no backward follows */
 #define TIC_EPI_ADDAUX 7  /* out = bf16(bf16(acc) + aux), aux bf16 [M, N]; out == aux allowed (in place)   ResNet: input gradient of a 1x1
                            * convolution added to the gradient of the block's identity branch (TIC/ResNet/model.py:113, out += identity) */
 
@@ -293,6 +294,9 @@ typedef struct {
 int tic_vit_refresh_weights(const TicVitState* st, int transposes_only, tic_stream_t stream);
 /* pixel_values [B,3,224,224] fp32 -> logits [B,C] fp32 (also kept in the workspace) */
 int tic_vit_forward(const TicVitState* st, const float* pixel_values, float* logits_out, tic_stream_t stream);
+/* the same forward when NO backward will follow (validate_step / serve / full_judge under torch.no_grad): fc1 stores only gelu(u),
+ * not the derivative the backward would read (TIC_EPI_GELU_ONLY); identical logits */
+int tic_vit_forward_infer(const TicVitState* st, const float* pixel_values, float* logits_out, tic_stream_t stream);
 /* backward in three phases so the caller can overlap gradient all-reduce per bucket:
  *   head (classifier + final LN), layer l = L-1 .. 0, embeddings.  grads are ACCUMULATED into st->grads. */
 int tic_vit_backward_head(const TicVitState* st, const float* dlogits, tic_stream_t stream);

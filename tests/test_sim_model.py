@@ -155,3 +155,22 @@ def test_stale_activations_are_detected_not_differentiated():
     m.zero_grad()
     b.backward()
     assert torch.equal(g1, refs[0]) and torch.equal(m._engine.grads, refs[1])
+
+
+def test_inference_forward_equals_training_forward_and_refuses_backward(golden_dir):
+    """under torch.no_grad the forward takes the inference form (fc1 stores gelu(u) only): same logits bit for bit; a backward on
+    those activations is refused instead of reading a stale derivative"""
+    gold = np.load(f"{golden_dir}/vit_tiny.npz")
+    spec, params = _tiny(gold)
+    m = ViT(10, pretrained=False, model_name="tiny", backend=SimBackend())
+    m.load_state_dict(params)
+    x = torch.from_numpy(gold["x"][:2])
+    train_logits = m(x).logits.detach().clone()
+    with torch.no_grad():
+        infer_logits = m(x).logits
+    assert torch.equal(train_logits, infer_logits)
+    e = m._engine
+    with pytest.raises(RuntimeError, match="inference mode"):
+        e.backward(torch.zeros_like(infer_logits))
+    logits = m(x).logits   # a training forward at the same batch size clears the mark
+    logits.sum().backward()

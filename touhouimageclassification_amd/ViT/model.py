@@ -195,8 +195,8 @@ class TicViTForImageClassification(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._params_by_name.values())
         if needs_grad:
             logits = _VitFunction.apply(self._anchor, x, self)
-        else:
-            logits = self._engine.forward(x)
+        else:   # no backward can follow: fc1 skips storing gelu'(u)
+            logits = self._engine.forward_infer(x)
         loss = None
         if labels is not None:
             loss = torch.nn.functional.cross_entropy(logits, labels)

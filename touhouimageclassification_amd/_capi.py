@@ -103,6 +103,7 @@ SIGNATURES = {
     "tic_vit_layout": ([C.POINTER(TicVitDims), C.POINTER(TicVitLayout)], I),
     "tic_vit_refresh_weights": ([C.POINTER(TicVitState), I, P], I),
     "tic_vit_forward": ([C.POINTER(TicVitState), P, P, P], I),
+    "tic_vit_forward_infer": ([C.POINTER(TicVitState), P, P, P], I),
     "tic_vit_backward_head": ([C.POINTER(TicVitState), P, P], I),
     "tic_vit_backward_layer": ([C.POINTER(TicVitState), I, P], I),
     "tic_vit_backward_embed": ([C.POINTER(TicVitState), P], I),

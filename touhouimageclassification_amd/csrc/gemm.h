@@ -120,6 +120,11 @@ TIC_DEV f32x4 epi_store(const GemmNtParams& p, int m, int n, f32x4 v, EpiExtra e
         const float d2 = bfround(v[2]) * gelu_erf_grad(u2), d3 = bfround(v[3]) * gelu_erf_grad(u3);
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(d0, d1), pack2bf(d2, d3)};
         return f32x4{d0, d1, d2, d3};
+    } else if (EPI == TIC_EPI_GELU_ONLY) {
+        float g[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[r] = gelu_erf(bfround(v[r]));
+        *reinterpret_cast<u32x2*>(p.out2 + o) = u32x2{pack2bf(g[0], g[1]), pack2bf(g[2], g[3])};
     } else if (EPI == TIC_EPI_GELU_DG) {
         const GeluPair lo = gelu_pair(f32x2{bfround(v[0]), bfround(v[1])}), hi = gelu_pair(f32x2{bfround(v[2]), bfround(v[3])});
         *reinterpret_cast<u32x2*>(p.out + o) = u32x2{pack2bf(lo.dg[0], lo.dg[1]), pack2bf(hi.dg[0], hi.dg[1])};

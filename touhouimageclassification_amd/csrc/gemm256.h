@@ -142,6 +142,11 @@ TIC_DEV void g256_finish_bf16(const GemmNtParams& p, int tid, int m0, int n0, u3
                 for (int j = 0; j < 4; ++j) g[j] = pack2bf(gelu_erf(bf_lo(u[j])), gelu_erf(bf_hi(u[j])));
                 st_u4<NTS>(p.out + o, u);
                 st_u4<NTS>(p.out2 + o, g);
+            } else if (EPI == TIC_EPI_GELU_ONLY) {
+                u32x4 g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = pack2bf(gelu_erf(bf_lo(u[j])), gelu_erf(bf_hi(u[j])));
+                st_u4<NTS>(p.out2 + o, g);
             } else if (EPI == TIC_EPI_GELU_DG) {
                 u32x4 g, dg;
 #pragma unroll

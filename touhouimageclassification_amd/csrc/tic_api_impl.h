@@ -377,6 +377,10 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
             TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_DGELU needs out_bf16 and aux_bf16");
             TIC_GEMM_NT_LAUNCH_P(TIC_EPI_DGELU);
             break;
+        case TIC_EPI_GELU_ONLY:
+            TIC_REQUIRE(out2_bf16, "gemm_nt: EPI_GELU_ONLY needs out2_bf16");
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_GELU_ONLY);
+            break;
         case TIC_EPI_GELU_DG:
             TIC_REQUIRE(out_bf16 && out2_bf16, "gemm_nt: EPI_GELU_DG needs out_bf16 and out2_bf16");
             TIC_GEMM_NT_LAUNCH_P(TIC_EPI_GELU_DG);
@@ -1188,7 +1192,14 @@ extern "C" int tic_vit_refresh_weights(const TicVitState* st, int transposes_onl
     return TIC_OK;
 }
 
+static int vit_forward_impl(const TicVitState* st, const float* x, float* logits_out, bool infer, tic_stream_t s);
 extern "C" int tic_vit_forward(const TicVitState* st, const float* x, float* logits_out, tic_stream_t s) {
+    return vit_forward_impl(st, x, logits_out, false, s);
+}
+extern "C" int tic_vit_forward_infer(const TicVitState* st, const float* x, float* logits_out, tic_stream_t s) {
+    return vit_forward_impl(st, x, logits_out, true, s);
+}
+static int vit_forward_impl(const TicVitState* st, const float* x, float* logits_out, bool infer, tic_stream_t s) {
     VitCtx c;
     TIC_TRY(vit_ctx(st, c));
     TIC_REQUIRE(x, "vit_forward: null pixel_values");
@@ -1212,7 +1223,9 @@ extern "C" int tic_vit_forward(const TicVitState* st, const float* x, float* log
         TIC_TRY(tic_attention_fwd(a + y.qkv, a + y.o, (float*)(a + y.lse), B, (int)c.H, N, 0.125f, s));
         TIC_TRY(tic_gemm_nt_bf16(a + y.o, lw + y.wo, M, D, D, TIC_EPI_RESID, lp + y.bo, nullptr, nullptr, hmid, hin, nullptr, nullptr, 0, s));
         TIC_TRY(tic_layernorm_fwd(hmid, D, lp + y.ln2_g, lp + y.ln2_b, a + y.a2, (float*)(a + y.mean2), (float*)(a + y.rstd2), M, D, c.eps, s));
-        TIC_TRY(tic_gemm_nt_bf16(a + y.a2, lw + y.w1, M, F, D, TIC_EPI_GELU_DG, lp + y.b1, a + y.u, a + y.g, nullptr, nullptr, nullptr, nullptr, 0, s));
+        // fc1 + GELU: gelu'(u) (-> a.u) is stored for the backward only
+        TIC_TRY(tic_gemm_nt_bf16(a + y.a2, lw + y.w1, M, F, D, infer ? TIC_EPI_GELU_ONLY : TIC_EPI_GELU_DG, lp + y.b1, infer ? nullptr : a + y.u, a + y.g, nullptr,
+                                 nullptr, nullptr, nullptr, 0, s));
         TIC_TRY(tic_gemm_nt_bf16(a + y.g, lw + y.w2, M, D, F, TIC_EPI_RESID, lp + y.b2, nullptr, nullptr, hout, hmid, nullptr, nullptr, 0, s));
     }
     float* hL = (float*)(c.ws + y.hs + c.L * y.hs_stride);

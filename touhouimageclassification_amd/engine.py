@@ -63,6 +63,7 @@ class VitEngine:
         self.live_graphs = 1
         self._gen = 0
         self._slot_gen: Dict[Tuple[int, int], int] = {}
+        self._slot_infer: set = set()   # (B, slot) whose last forward ran in inference mode: no backward on those
         self._slot_next: Dict[int, int] = {}
 
     # ---- layout ------------------------------------------------------------------------------------
@@ -139,6 +140,7 @@ class VitEngine:
         self.w16 = self.wT16 = None
         self._ws.clear()
         self._slot_gen.clear()
+        self._slot_infer.clear()
         self._weights_version = -1
         self.device = flat.device
 
@@ -163,6 +165,7 @@ class VitEngine:
         while len(self._ws) >= 2 * max(1, self.live_graphs):
             old, _ = self._ws.popitem(last=False)
             self._slot_gen.pop(old, None)   # a backward that still needs it will raise (stale stamp), not read garbage
+            self._slot_infer.discard(old)
         ws = torch.empty(lay.ws_bytes, dtype=torch.uint8, device=self.params.device)
         ws[lay.nt_scratch + _capi.NT_SCRATCH_BYTES - _capi.NT_FLAG_BYTES:lay.nt_scratch + _capi.NT_SCRATCH_BYTES].zero_()   # split-K flag words: zero ONCE
         st = _capi.TicVitState(self._dims(B), self.params.data_ptr(), self.grads.data_ptr(), self.w16.data_ptr(),
@@ -194,7 +197,12 @@ class VitEngine:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.forward_stamped(x)[0]
 
-    def forward_stamped(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
+    def forward_infer(self, x: torch.Tensor) -> torch.Tensor:
+        """forward that NO backward will follow (torch.no_grad callers: validate_step, serve, full_judge): fc1 stores gelu(u) only, not
+        the derivative the backward reads.  A backward on these activations raises."""
+        return self.forward_stamped(x, infer=True)[0]
+
+    def forward_stamped(self, x: torch.Tensor, infer: bool = False) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
         """-> (logits, stamp).  `stamp` = (B, workspace slot, generation) identifies the saved activations this forward
         left behind; pass it to `backward` to have a later overwrite (another forward at the same batch size, an
         eviction) detected instead of differentiated."""
@@ -205,9 +213,10 @@ class VitEngine:
         _, st, _ = self._state(B, slot)
         self.refresh_weights_if_needed()
         logits = torch.empty(B, self.C, dtype=torch.float32, device=x.device)
-        self.backend.call("tic_vit_forward", ctypes.byref(st), x.data_ptr(), logits.data_ptr(), self.backend.stream())
+        self.backend.call("tic_vit_forward_infer" if infer else "tic_vit_forward", ctypes.byref(st), x.data_ptr(), logits.data_ptr(), self.backend.stream())
         self._gen += 1
         self._slot_gen[(B, slot)] = self._gen
+        (self._slot_infer.add if infer else self._slot_infer.discard)((B, slot))
         return logits, (B, slot, self._gen)
 
     def backward(self, dlogits: torch.Tensor, bucket_hook: Optional[Callable[[str, int, int], None]] = None,
@@ -217,8 +226,13 @@ class VitEngine:
         B = dlogits.shape[0]
         if stamp is None:   # fused step: the forward that just ran
             slot = (self._slot_next.get(B, 1) - 1) % max(1, self.live_graphs)
+            if (B, slot) in self._slot_infer:
+                raise RuntimeError("TIC ViT backward: the last forward at this batch size ran in inference mode (torch.no_grad): its "
+                                   "activations lack what the backward reads")
         else:
             slot = stamp[1]
+            if (B, slot) in self._slot_infer and self._slot_gen.get((B, slot)) == stamp[2]:
+                raise RuntimeError("TIC ViT backward: this forward ran in inference mode (torch.no_grad)")
             if stamp[0] != B or self._slot_gen.get((B, slot)) != stamp[2]:
                 raise RuntimeError(
                     "TIC ViT backward: the activations saved by this forward are gone -- another forward at batch size "
