@@ -33,27 +33,21 @@ typedef void* tic_stream_t; /* hipStream_t */
 #define TIC_ABI_VERSION 1
 int tic_version(void);
 const char* tic_last_error_string(void);
-/* process-wide knobs for A/B measurements (never needed for correct results):
- *   "gemm_tile"  0 (auto) | 128 | 256       which NT / TN tile family to use
+/* Route selection for the parity tests -- SIX knobs, never needed for correct results: each chooses between numerically equivalent
+ * forms of a kernel so that a test can force every one of them.  They are plain process-wide ints read when a launch is enqueued:
+ * set them while no other host thread is inside a tic_* call (they are NOT per-stream or per-call state; the default of each is what
+ * the training step uses).  Unknown names / values return TIC_EINVAL.
+ *   "gemm_tile"  0 (auto) | 128 | 256       NT / TN tile family (auto: 256x256 from 128 tiles up)
+ *   "gemm_split" -1 (auto) | 0 | 2 | 4      split-K form of the 128x128 NT kernel (needs tic_gemm_nt_scratch; never under stream capture);
+ *                                           auto: two parts where 2 x tiles fit 512 workgroups and a part keeps >= 16 K tiles
  *   "tn_streamk" 1 (256 shares) | 0 | n     stream-K split of the grouped dW launch
- *   "tn_phase"   1 | 0                      phase-aligned vs flat stream-K split
- *   "tn_slab"    1 | 0                      few-tile weight gradients through the tic_gemm_tn_scratch slab vs stream-K atomics
- *   "tn_parts"   -1 (auto) | 0 | 2..8       tile counts without a phase-aligned split (ViT-B: 108): every tile in n equal row parts (auto: 256 / tiles) | flat stream-K
+ *   "tn_parts"   -1 (auto) | 0 | 2..8       grouped dW whose tile count has no phase-aligned split (ViT-B: 108 tiles): every tile in n equal
+ *                                           row parts (auto: 256 / tiles) | 0: flat stream-K
  *   "tn_mfma"    0 (auto) | 16 | 32         MFMA shape of the grouped dW stream-K launch (16x16x32 for long reductions, else 32x32x16)
- *   "tn_block"   -1 (auto) | 0 | n          tile-walk block width of that launch (XCD-sized blocks | row-major | fixed)
- *   "gemm_big_tiles" 128                    fewest 256x256 tiles for which the 256x256 NT kernel is chosen (below: the 128x128 kernel)
- *   "tn_streamk_min_steps" 128              fewest 64-row reduction steps for which the grouped dW launch is stream-K split (below: one workgroup per tile)
- *   "ln_bwd_rows" 2                         LayerNorm backward: fewest rows per wave
- *   "gemm_split" -1 (auto) | 0 | 2 | 4       split-K forms of the NT kernels (need tic_gemm_nt_scratch); auto: the 128x128 kernel in two parts where
- *                                            2 x tiles fit 512 workgroups and a part keeps >= 16 K tiles, the 256x256 kernel only at exactly gemm_big_tiles tiles
- *   "gemm_persist" 0 | 1                    persistent form of the 256x256 NT kernel (measured slower: off)
- *   "gemm_pgrid" 256                        its grid (tests)
  *   "stream_nt"  bit mask, default 13       non-temporal cache policy: 1 LayerNorm, 2 AdamW, 4 GEMM epilogue stores, 8 epilogue operand loads
- *   "attn_fwd_waves" 8 | 4                   waves per (image, head) workgroup of the attention forward
- *   "gemm_stagger" -1 (auto) | 0 | n        s_sleep rounds by which every other first-wave workgroup of the 256x256 NT kernel starts late
- * Builds that produce garbage by construction (parts of the GEMM main loops compiled out, "gemm_dbg") and the in-kernel stage
- * stamps exist only in the measurement library libtic_hip_dbg.so (-DTIC_MEASURE, `python -m touhouimageclassification_amd.build dbg`;
- * tools/gemm_dbg.py, tools/tile_timeline.py), never in libtic_hip.so. */
+ * Everything that was only ever an A/B measurement (tile-walk shapes, grid caps, stagger, the 256x256 kernel's split-K form, main
+ * loops with parts compiled out, in-kernel stage stamps) exists in the measurement library libtic_hip_dbg.so alone (-DTIC_MEASURE,
+ * `python -m touhouimageclassification_amd.build dbg`; tools/ab_step.py, tools/gemm_dbg.py, tools/tile_timeline.py). */
 int tic_set_option(const char* name, int value);
 /* Live timing of the step's dominant kernel (the grouped dW launch of tic_gemm_tn_group_bf16 / tic_vit_backward_layer): while
  * enabled, HIP events are recorded on the launch stream around every such launch (up to 8192); read() waits for them and
@@ -63,10 +57,14 @@ int tic_probe_stream(const float* src, float* dst, float* sink, long n, int bloc
 int tic_kernel_timer_enable(int on);
 int tic_kernel_timer_read(int* launches, float* total_ms);
 
-/* Scratch for the split-K form of the 256x256 NT kernel (launches with few output tiles and a long reduction: small batches):
+/* Scratch for the split-K form of the NT kernel (launches with few output tiles and a long reduction: 8-16 images per GPU):
  * caller-owned, at least TIC_NT_SCRATCH_BYTES, 16-byte aligned; its last 4 KiB are flag words the caller zeroes ONCE.  Registered per
  * host thread and used by every tic_gemm_nt_* / tic_vit_* call of that thread until replaced (NULL: never split); calls that share a
- * scratch must be on ONE stream.  tic_vit_* use the scratch inside their workspace (TicVitLayout.nt_scratch) by themselves. */
+ * scratch must be on ONE stream.  tic_vit_* use the scratch inside their workspace (TicVitLayout.nt_scratch) by themselves.
+ * A consumer workgroup whose bounded poll for a producer's flag runs out does not pass silently: it stores a code into a host-mapped
+ * error word (64 bytes of pinned host memory the library maps on the first registration -- its only allocation) and EVERY later tic_*
+ * call returns TIC_ELAUNCH until a scratch is registered again.  Launches enqueued while the stream is being captured into a HIP
+ * graph never split (the flag value counts launches and would be replayed). */
 #define TIC_NT_SCRATCH_BYTES ((size_t)192 * 32 * 512 * 16 + 4096)
 int tic_gemm_nt_scratch(void* scratch, size_t bytes);
 
@@ -219,20 +217,23 @@ int tic_im2col_bf16(const void* x, void* col, int B, int H, int W, int Ci, int k
 int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, int accumulate,
                     tic_stream_t stream);
 /* BatchNorm2d over [M, C] bf16 (+ optional residual add, + optional ReLU): y = relu(bn(x) + identity).  train != 0: batch
- * statistics, running stats (unbiased var) and num_batches_tracked updated; else running stats.  scratch2c: 2*C floats that are
- * ZERO on entry and left zero on return (the kernels accumulate into them and clear them: one zero-filled buffer per layer,
- * allocated once, serves every forward and backward call -- no memset per call).  model.py:51-52,60-61,99-113,150-151 */
+ * statistics, running stats (unbiased var) and num_batches_tracked updated; else running stats.  scratch: caller-owned,
+ * >= tic_batchnorm_scratch_bytes(M, C), contents arbitrary on entry and undefined on return -- the row splits of the column
+ * reductions STORE their partial sums there and the next kernel adds them in a fixed order (no atomics: statistics, activations and
+ * activation gradients are bit-reproducible run to run; no zero-on-entry contract, one buffer may serve every layer of a stream).
+ * model.py:51-52,60-61,99-113,150-151 */
+size_t tic_batchnorm_scratch_bytes(long M, int C);
 int tic_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                      int64_t* num_batches, float* mean, float* rstd, float* scratch2c, const void* identity, void* y, long M, int C,
-                      float eps, float momentum, int train, int relu, tic_stream_t stream);
+                      int64_t* num_batches, float* mean, float* rstd, void* scratch, size_t scratch_bytes, const void* identity, void* y,
+                      long M, int C, float eps, float momentum, int train, int relu, tic_stream_t stream);
 /* dz = dy * [y > 0] (y_or_null = the block output when a ReLU follows); dx = BN'(dz); dskip (optional) (+)= dz; dgamma/dbeta += */
 int tic_batchnorm_bwd(const void* dy, const void* y_or_null, const void* x, const float* mean, const float* rstd, const float* gamma,
-                      float* scratch2c, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M, int C,
-                      tic_stream_t stream);
+                      void* scratch, size_t scratch_bytes, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M,
+                      int C, tic_stream_t stream);
 /* backward of y = relu(bn(x)) WITHOUT a residual add (the first one or two BatchNorms of a block): the ReLU mask is recomputed from
  * x with the forward's own fp32 expression and bf16 rounding, so y is not read in either pass (12 instead of 16 B per element) */
 int tic_batchnorm_bwd_relu(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                           float* scratch2c, void* dx, float* dgamma, float* dbeta, long M, int C, tic_stream_t stream);
+                           void* scratch, size_t scratch_bytes, void* dx, float* dgamma, float* dbeta, long M, int C, tic_stream_t stream);
 int tic_maxpool3x3s2_fwd(const void* x, void* y, int B, int H, int W, int C, tic_stream_t stream);                       /* model.py:152 */
 int tic_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C, tic_stream_t stream);
 /* the same pool, with the window position (ky*3 + kx) of the first maximum saved as one byte per output element; the backward then
@@ -243,8 +244,8 @@ int tic_maxpool3x3s2_bwd_idx(const void* idx_u8, const void* dy, void* dx, int B
  * storing relu(bn(x)); bit-identical to tic_batchnorm_fwd(relu) + tic_maxpool3x3s2_fwd_idx.  Backward: tic_maxpool3x3s2_bwd_idx, then
  * tic_batchnorm_bwd_relu on x */
 int tic_bn_relu_maxpool_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
-                            float* mean, float* rstd, float* scratch2c, void* y_pool, void* idx_u8_or_null, int B, int H, int W, int C, float eps,
-                            float momentum, int train, tic_stream_t stream);
+                            float* mean, float* rstd, void* scratch, size_t scratch_bytes, void* y_pool, void* idx_u8_or_null, int B, int H, int W,
+                            int C, float eps, float momentum, int train, tic_stream_t stream);   /* scratch: as tic_batchnorm_fwd, M = B H W */
 int tic_avgpool_fwd(const void* x, void* y, int B, int HW, int C, tic_stream_t stream);                                  /* model.py:164,222 */
 int tic_avgpool_bwd(const void* dy, void* dx, int B, int HW, int C, tic_stream_t stream);
 int tic_add_bf16(void* a, const void* b, long n, tic_stream_t stream); /* a += b */

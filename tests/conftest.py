@@ -15,3 +15,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _headroom_log(request):
+    """every tolerance assertion logs observed / allowed (tests/headroom.py); written on a GPU box only"""
+    from tests import headroom
+    headroom.install()
+    headroom.set_test(request.node.nodeid)
+    yield
+    headroom.set_test("")

@@ -62,14 +62,17 @@ def check_gemm_nt_gelu_resid_dgelu_patch(env, N=128, K=128, imgs=3, Pn=50):
     torch.testing.assert_close(dg5.float(), u64.grad.float(), atol=5e-3, rtol=8e-3)   # bf16 rounding of gelu'
     d6, cs6 = torch.empty(M, N, dtype=torch.bfloat16, device=dev), torch.zeros(N, device=dev)
     call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), M, N, K, 6, None, ptr(d6), None, None, None, ptr(dg5), None, 0, ptr(cs6), None)
-    torch.testing.assert_close(d6.float(), bfr(bfr(A.float() @ B.float().t()) * dg5.float()), atol=2e-3, rtol=1.6e-2)   # two bf16 ulps: the reference product rounds too
+    # both sides round twice (the product, then product x derivative) from accumulators that differ in their fp32 summation order: up
+    # to 2 bf16 ulps (2 x 2^-7 relative) apart by construction; the band is twice that (tests/headroom.py: no band more than half used)
+    torch.testing.assert_close(d6.float(), bfr(bfr(A.float() @ B.float().t()) * dg5.float()), atol=4e-3, rtol=3.2e-2)
     torch.testing.assert_close(d6.float(), uu.grad, atol=0.03, rtol=0.03)
     torch.testing.assert_close(cs6, d6.float().sum(0), atol=0.05, rtol=0.02)
     # ADDAUX (7): the product added onto a bf16 tensor IN PLACE, exactly bf16(bf16(acc) + aux) = what a separate add pass would store
     acc7 = bf(rnd(M, N))
     want7 = bfr(bfr(A.float() @ B.float().t()) + acc7.float())
     call("tic_gemm_nt_bf16", ptr(A), ptr(B), M, N, K, 7, None, ptr(acc7), None, None, None, ptr(acc7), None, 0, None)
-    torch.testing.assert_close(acc7.float(), want7, atol=2e-2, rtol=1.6e-2)   # one bf16 ulp of the PRODUCT (it rounds before the add, which may cancel)
+    # one bf16 ulp of the PRODUCT (it rounds before the add, which may cancel) + one of the sum, by construction; the band is twice that
+    torch.testing.assert_close(acc7.float(), want7, atol=4e-2, rtol=3.2e-2)
     # patch epilogue: M = images * patches, rows remapped past the CLS slot
     pos = rnd(Pn + 1, N)
     h = torch.zeros(imgs * (Pn + 1), N, device=dev)
@@ -358,7 +361,7 @@ def check_fused_bias_gradients(env):
         env._call("tic_set_option", b"gemm_tile", tile)
         try:
             call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), M, N, K, 3, None, ptr(out), None, None, None, ptr(u), None, 0, ptr(cs), None)
-            torch.testing.assert_close(cs, 1 + out.float().sum(0), atol=0.05, rtol=0.02)
+            torch.testing.assert_close(cs, 1 + out.float().sum(0), atol=0.1, rtol=0.02)   # sums of the fp32 values vs sums of their bf16 roundings over M rows
             cs2 = torch.zeros(N, device=dev)
             bias = rnd(N)
             call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), M, N, K, 0, ptr(bias), ptr(out), None, None, None, None, None, 0, ptr(cs2), None)
@@ -459,46 +462,8 @@ def check_moe_ops(env, B=7, E=8, K=2, C=120):
         torch.testing.assert_close(dg.cpu(), gr.grad, atol=1e-7, rtol=1e-4)
 
 
-def check_persistent_nt_matches(env, M, N, K, pgrid):
-    """the persistent 256x256 NT kernel (gemm256p.h: one workgroup walks several tiles, the next tile's operands prefetched under
-    the second pass) against the one-tile-per-workgroup kernel: same fp32 accumulation order, so every epilogue it serves must be
-    BIT-identical, column sums included (those only up to the order of their atomics)"""
-    rnd, call, dev = env.rnd, env.call, env.dev
-    A, B, bias = bf(rnd(M, K, scale=0.3)), bf(rnd(N, K, scale=0.3)), rnd(N, scale=0.1)
-    aux = bf(rnd(M, N, scale=0.5))
-
-    def run(epi, persist):
-        env._call("tic_set_option", b"gemm_persist", persist)
-        o1 = torch.full((M, N), 3.0, device=dev).to(torch.bfloat16)
-        o2 = torch.full((M, N), 5.0, device=dev).to(torch.bfloat16)
-        cs = torch.zeros(N, device=dev)
-        has_cs = epi in (0, 3, 6)
-        call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), M, N, K, epi, None if epi in (3, 6) else ptr(bias), ptr(o1), ptr(o2) if epi in (1, 5) else None,
-             None, None, ptr(aux) if epi in (3, 6) else None, None, 0, ptr(cs) if has_cs else None, None)
-        return o1, o2, cs
-
-    env._call("tic_set_option", b"gemm_tile", 256)
-    env._call("tic_set_option", b"gemm_pgrid", pgrid)
-    try:
-        for epi in (0, 1, 5, 3, 6):
-            r1, r2, rcs = run(epi, 0)
-            for _ in range(2):
-                p1, p2, pcs = run(epi, 1)
-                assert torch.equal(p1, r1), (epi, "out")
-                if epi in (1, 5):
-                    assert torch.equal(p2, r2), (epi, "out2")
-                if epi in (0, 3, 6):
-                    torch.testing.assert_close(pcs, rcs, atol=1e-3 * max(1.0, float(rcs.abs().max())), rtol=1e-4)
-        ref = A.float() @ B.float().t() + bias           # and the plain epilogue against fp32 math
-        torch.testing.assert_close(run(0, 1)[0].float(), ref, atol=0.06, rtol=0.02)
-    finally:
-        env._call("tic_set_option", b"gemm_tile", 0)
-        env._call("tic_set_option", b"gemm_pgrid", 256)
-        env._call("tic_set_option", b"gemm_persist", 0)
-
-
-def check_splitk_nt(env, M, N, K, split, tile=256):
-    """the split-K form of the 256x256 NT kernel (2 or 4 workgroups per tile, fp32 partial accumulators handed over through a
+def check_splitk_nt(env, M, N, K, split, tile=128):
+    """the split-K form of the 128x128 NT kernel (2 or 4 workgroups per tile, fp32 partial accumulators handed over through a
     caller-owned scratch, flags that count launches) against the unsplit kernel and fp32 math: same single rounding to bf16, only the
     fp32 summation order differs"""
     from touhouimageclassification_amd import _capi
@@ -572,3 +537,39 @@ def check_gemm_tn_slab(env, M, N, K, slab_mb=64):
     tol = dict(atol=2e-3 * max(1.0, (M / 200) ** 0.5), rtol=1e-3)
     torch.testing.assert_close(Ca, ref, **tol)
     torch.testing.assert_close(Cs, ref + (ref - C0), atol=2 * tol["atol"], rtol=1e-3)
+
+
+def check_splitk_timeout_is_reported(env, M=200, N=256, K=512):
+    """a split-K consumer whose producer never publishes its flag must not sum an unwritten slab and report success.
+    Test builds can withhold part 0's flag ("nt_fault"): the consumer's bounded poll runs out, it stores 0xDEADxxxx into the host-mapped
+    error word, and every later call fails with TIC_ELAUNCH until a scratch is registered again (the caller re-zeroes the flags)."""
+    import pytest
+    from touhouimageclassification_amd import _capi
+    rnd, dev = env.rnd, env.dev
+    A, B, bias = bf(rnd(M, K, scale=0.3)), bf(rnd(N, K, scale=0.3)), rnd(N, scale=0.1)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    scratch = torch.zeros(_capi.NT_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+    args = (ptr(A), ptr(B), M, N, K, 0, ptr(bias), ptr(out), None, None, None, None, None, 0, None, None)
+    env._call("tic_set_option", b"gemm_tile", 128)
+    env._call("tic_set_option", b"gemm_split", 2)
+    env._call("tic_gemm_nt_scratch", ptr(scratch), scratch.numel())
+    try:
+        env.call("tic_gemm_nt_bf16_ex", *args)                       # healthy hand-off
+        ref = out.clone()
+        env._call("tic_set_option", b"nt_fault", 1)
+        with pytest.raises(Exception, match="timed out"):            # the faulty launch itself (simulator: synchronous) or the next call
+            env.call("tic_gemm_nt_bf16_ex", *args)
+            env.call("tic_gemm_nt_bf16_ex", *args)
+        env._call("tic_set_option", b"nt_fault", 0)
+        b16 = torch.empty(N, dtype=torch.bfloat16, device=dev)
+        with pytest.raises(Exception, match="timed out"):            # sticky: unrelated calls fail too
+            env.call("tic_cast_bf16", ptr(bias), ptr(b16), N, None)
+        scratch.zero_()
+        env._call("tic_gemm_nt_scratch", ptr(scratch), scratch.numel())   # re-registration clears the error
+        env.call("tic_gemm_nt_bf16_ex", *args)
+        assert torch.equal(out, ref)
+    finally:
+        env._call("tic_set_option", b"nt_fault", 0)
+        env._call("tic_gemm_nt_scratch", None, 0)
+        env._call("tic_set_option", b"gemm_tile", 0)
+        env._call("tic_set_option", b"gemm_split", -1)

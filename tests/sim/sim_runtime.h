@@ -331,9 +331,12 @@ TIC_DEV uint32_t uniform(uint32_t v) { return v; }
 TIC_DEV void atomic_addf(float* p, float v) { *p += v; }
 // workgroups run one after the other here (producers have the lower block indices): the hand-off is a plain store / compare
 TIC_DEV void flag_publish(unsigned* flag, unsigned value) { *flag = value; }
-TIC_DEV bool flag_wait(const unsigned* flag, unsigned value) {
-    if (*flag != value) sim::die("flag_wait: the producer workgroup has not run (block order)");
-    return true;
+// (a flag that does not hold the launch's value is what the GPU's bounded poll would time out on: reported through `err` as there)
+TIC_DEV bool flag_wait(const unsigned* flag, unsigned value, unsigned* err) {
+    if (*flag == value) return true;
+    if (!err) sim::die("flag_wait: the producer workgroup has not run (block order)");
+    *err = 0xDEAD0000u | (value & 0xFFFFu);
+    return false;
 }
 TIC_DEV float fast_exp2(float x) { return exp2f(x); }
 TIC_DEV float fast_rcp(float x) { return 1.0f / x; }

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import vit_oracle as vo
+from tests import headroom as hr
 from tests import kernel_checks as kc
 from tests.simlib import bf, bfr, ptr
 
@@ -65,7 +66,7 @@ def test_nt_gemm_epilogues_at_bench_m(env, N, K, epi):
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         cs = torch.zeros(N, device="cuda")
         call("tic_gemm_nt_bf16_ex", ptr(A), ptr(W), M, N, K, 6, None, ptr(out), None, None, None, ptr(aux), None, 0, ptr(cs), None)
-        torch.testing.assert_close(out[rows].float(), bfr(bfr(acc) * aux[rows].float()), atol=5e-3, rtol=1.6e-2)
+        torch.testing.assert_close(out[rows].float(), bfr(bfr(acc) * aux[rows].float()), atol=5e-3, rtol=3.2e-2)   # 2 bf16 ulps by construction (kernel_checks.py), band 4
         torch.testing.assert_close(cs, out.float().sum(0), atol=2e-3 * float(out.float().abs().sum(0).max()), rtol=1e-3)
 
 
@@ -150,9 +151,9 @@ def test_vit_large_step_at_bench_batch_ties_to_oracle_and_to_small_batches():
     logits = e.forward(xd)
     with torch.no_grad():
         ref = vo.forward(params, x[pick], spec)
-    torch.testing.assert_close(logits[pick].cpu(), ref, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(logits[pick].cpu(), ref, atol=2e-2 * max(1.0, float(ref.abs().max())), rtol=2e-2)   # bf16 GEMM I/O: the error scales with the logits
     loss, dl = ops.softmax_xent(logits, yd)
-    assert abs(float(loss) - float(vo.cross_entropy(logits.cpu(), y))) < 1e-4
+    hr.le("test_gpu_benchshape.py:155", abs(float(loss) - float(vo.cross_entropy(logits.cpu(), y))), 1e-4)
     e.grads.zero_()
     e.backward(dl)
     big = e.grads.clone()
@@ -168,7 +169,105 @@ def test_vit_large_step_at_bench_batch_ties_to_oracle_and_to_small_batches():
     acc /= 4
     for name, a, b in e.buckets():   # per DP bucket (head, every layer, embeddings): relative L2 error of the gradient
         rel = ((big[a:b] - acc[a:b]).norm() / acc[a:b].norm()).item()
-        assert rel < 2e-2, (name, rel)
+        hr.le("test_gpu_benchshape.py:171", rel, 2e-2, ctx=(name, rel))
+    opt = FusedAdamW(model, lr=1e-5, weight_decay=0.01)
+    before = e.params.clone()
+    fused_train_step(model, opt, xd, yd, None)
+    moved = (e.params - before).abs()
+    assert float(moved.max()) <= 1.3e-5 and all(float(moved[a:b].max()) > 0 for _, a, b in e.buckets())
+
+
+# ---- BASELINE config 2: ViT-Base/16, global batch 256 on one GPU (M = 256 x 197 = 50 432 rows) ---------------------------------
+B_CFG2 = 256
+M2 = B_CFG2 * N_TOK          # 50 432
+DB, FB = 768, 3072
+
+
+def test_vit_base_grouped_dw_equal_parts_split_at_config2_m(env):
+    """ViT-B's four weight gradients are 108 tiles of 256 x 256: not a multiple of the 8 XCDs, so the launch takes the equal-parts
+    split (`tn_parts`, two row halves per tile, 216 workgroups) instead of the phase-aligned stream-K one.  Checked at config 2's
+    M = 50 432 against full fp32 matmuls over all rows, default routing and every forced form of the split."""
+    from touhouimageclassification_amd._lib import call
+    shapes = [(DB, FB), (FB, DB), (DB, DB), (3 * DB, DB)]
+    kc.check_gemm_tn_group(env, M2, shapes)          # what the step launches
+    try:
+        for parts in (2, 3, 0):                      # forced: 2 / 3 equal row parts per tile, the flat stream-K split
+            call("tic_set_option", b"tn_parts", parts)
+            kc.check_gemm_tn_group(env, M2, shapes)
+    finally:
+        call("tic_set_option", b"tn_parts", -1)
+
+
+@pytest.mark.parametrize("N,K,epi", [(3 * DB, DB, "bf16"), (DB, FB, "resid"), (FB, DB, "gelu_dg")])
+def test_vit_base_nt_gemms_at_config2_m(env, N, K, epi):
+    """N = 768 = 3 column tiles x 197 row tiles = 591 tiles (2.3 rounds of the 256 CUs), K = 768 = 12 K tiles: the shapes only ViT-B has"""
+    rnd, call = env.rnd, env.call
+    A, W, bias = bf(rnd(M2, K, scale=0.5)), bf(rnd(N, K, scale=0.05)), rnd(N, scale=0.1)
+    r = torch.cat([torch.arange(0, 300), torch.arange(M2 - 300, M2), torch.randint(0, M2, (1500,), generator=env.gen)]).unique().cuda()
+    acc = A[r].float() @ W.float().t()
+    if epi == "bf16":
+        out = torch.empty(M2, N, dtype=torch.bfloat16, device="cuda")
+        call("tic_gemm_nt_bf16", ptr(A), ptr(W), M2, N, K, 0, ptr(bias), ptr(out), None, None, None, None, None, 0, None)
+        torch.testing.assert_close(out[r].float(), acc + bias, atol=0.03, rtol=0.02)
+    elif epi == "resid":
+        resid, out = rnd(M2, N), torch.empty(M2, N, device="cuda")
+        call("tic_gemm_nt_bf16", ptr(A), ptr(W), M2, N, K, 2, ptr(bias), None, None, ptr(out), ptr(resid), None, None, 0, None)
+        torch.testing.assert_close(out[r], resid[r] + bfr(acc + bias), atol=0.03, rtol=0.02)
+    else:
+        dg, g = torch.empty(M2, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M2, N, dtype=torch.bfloat16, device="cuda")
+        call("tic_gemm_nt_bf16", ptr(A), ptr(W), M2, N, K, 5, ptr(bias), ptr(dg), ptr(g), None, None, None, None, 0, None)
+        u = bfr(acc + bias).double().requires_grad_(True)
+        gu = torch.nn.functional.gelu(u)
+        gu.sum().backward()
+        torch.testing.assert_close(g[r].float(), gu.detach().float(), atol=0.02, rtol=0.02)
+        torch.testing.assert_close(dg[r].float(), u.grad.float(), atol=0.02, rtol=0.02)
+
+
+def test_vit_base_step_at_config2_batch_ties_to_oracle_and_to_small_batches():
+    """One ViT-B/16 C=10 training step at B = 256 (BASELINE config 2): the logits of a 4-image slice against the fp32 CPU oracle on
+    those images, the loss against the oracle's CE of the GPU logits, the 256-image gradient against the mean of its four 64-image
+    quarters per DP bucket (M = 12 608, the regime of the operator / golden tests), and the fused step moves every bucket."""
+    from touhouimageclassification_amd.ViT.model import ViT
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from touhouimageclassification_amd.step import fused_train_step
+    from touhouimageclassification_amd import ops
+    dev = torch.device("cuda")
+    C = 10
+    spec = vo.ViTSpec(**vo.VIT_BASE, num_labels=C)
+    params = vo.randomize_small_params(vo.init_params(spec, seed=30), seed=31)
+    model = ViT(C, pretrained=False, model_name="google/vit-base-patch16-224")
+    model.load_state_dict(params)
+    model.to(dev)
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(B_CFG2, 3, 224, 224, generator=g)
+    y = torch.randint(0, C, (B_CFG2,), generator=g)
+    xd, yd = x.to(dev), y.to(dev)
+    pick = [0, 1, 254, 255]
+    e = model._engine
+    logits = e.forward(xd)
+    with torch.no_grad():
+        ref = vo.forward(params, x[pick], spec)
+    torch.testing.assert_close(logits[pick].cpu(), ref, atol=2e-2 * max(1.0, float(ref.abs().max())), rtol=2e-2)   # bf16 GEMM I/O: the error scales with the logits
+    margin = ref.sort(-1, descending=True).values
+    decided = (margin[:, 0] - margin[:, 1]) > 4e-2
+    assert torch.equal(logits[pick].cpu().argmax(-1)[decided], ref.argmax(-1)[decided])
+    loss, dl = ops.softmax_xent(logits, yd)
+    hr.le("loss vs oracle CE of the same logits", abs(float(loss) - float(vo.cross_entropy(logits.cpu(), y))), 1e-4)
+    e.grads.zero_()
+    e.backward(dl)
+    big = e.grads.clone()
+    assert torch.isfinite(big).all()
+    acc = torch.zeros_like(big)
+    q = B_CFG2 // 4
+    for i in range(4):
+        lg = e.forward(xd[i * q:(i + 1) * q].contiguous())
+        _, dli = ops.softmax_xent(lg, yd[i * q:(i + 1) * q].contiguous())
+        e.grads.zero_()
+        e.backward(dli)
+        acc += e.grads
+    acc /= 4
+    for name, a, b in e.buckets():
+        hr.le(f"bucket {name}: 256-image gradient vs mean of quarters", ((big[a:b] - acc[a:b]).norm() / acc[a:b].norm()).item(), 2e-2)
     opt = FusedAdamW(model, lr=1e-5, weight_decay=0.01)
     before = e.params.clone()
     fused_train_step(model, opt, xd, yd, None)

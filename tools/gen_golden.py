@@ -7,7 +7,7 @@ Pins the CPU oracle (oracle/vit_oracle.py, oracle/resnet_oracle.py) to the real 
             (transformers 5.15.0 as installed; the reference pins no version).
   * ResNet: the reference's own TIC/ResNet/model.py imported from /root/reference.
 The fixtures are DATA (inputs, weights for the tiny configs, expected outputs); no
-reference source text is stored.  Usage:  python tools/gen_golden.py [vit|resnet|all]
+reference source text is stored.  Usage:  python tools/gen_golden.py [vit|resnet|resnet_units|aug|all]
 """
 import os
 import sys
@@ -164,6 +164,113 @@ def gen_resnet():
         np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **out)
 
 
+def gen_resnet_units():
+    """One-layer-deep ResNet goldens: single modules of the reference's own TIC/ResNet/model.py run in float64 --
+    `conv3x3` (:6-9, stride 1 and 2), `conv1x1` (:12-14, stride 2), the 7x7 stem convolution and its bn1 -> relu -> maxpool tail
+    (:148-152), a train-mode BatchNorm2d + ReLU with and without the residual add (:99-113), `Bottleneck` without and with the
+    stride-2 downsample branch (:66-115, :193-197) and `BasicBlock` (:17-63) -- forward AND every gradient.  One layer deep there is
+    no chaotic amplification, so the GPU / simulator tests hold them to tight fixed tolerances (cos >= 0.995).  All inputs and
+    weights are bf16-representable, so the only differences are fp32 accumulation and the bf16 storage of results."""
+    sys.path.insert(0, "/root/reference")
+    from TIC.ResNet import model as ref
+    g = torch.Generator().manual_seed(11)
+    bfr = lambda t: t.to(torch.bfloat16).double()                                    # noqa: E731
+    rnd = lambda *s, scale=1.0: bfr(torch.randn(*s, generator=g) * scale)            # noqa: E731
+    out = {}
+
+    def put(prefix, **kw):
+        for k, v in kw.items():
+            if torch.is_tensor(v) and k in ("x", "w", "dy", "ident") and torch.equal(v.detach(), bfr(v.detach())):
+                out[f"{prefix}/{k}:bf16"] = v.detach().to(torch.bfloat16).view(torch.int16).numpy()   # exact, half the bytes
+            else:
+                out[f"{prefix}/{k}"] = v.detach().numpy().astype(np.float32) if torch.is_tensor(v) else np.asarray(v)
+
+    def conv_case(tag, mod, x, geom):
+        mod = mod.double()
+        with torch.no_grad():
+            mod.weight.copy_(bfr(mod.weight * 1.0))
+        x = x.clone().requires_grad_(True)
+        y = mod(x)
+        dy = rnd(*y.shape, scale=0.5)
+        y.backward(dy)
+        put(tag, x=x, w=mod.weight, y=y, dy=dy, dx=x.grad, dw=mod.weight.grad, geom=np.array(geom))
+
+    torch.manual_seed(21)
+    conv_case("conv3x3_s1", ref.conv3x3(64, 64, 1), rnd(2, 64, 12, 12), (64, 64, 3, 1, 1))
+    conv_case("conv3x3_s2", ref.conv3x3(64, 128, 2), rnd(2, 64, 12, 12), (64, 128, 3, 2, 1))
+    conv_case("conv1x1_s2", ref.conv1x1(128, 256, 2), rnd(2, 128, 8, 8), (128, 256, 1, 2, 0))
+    net = ref.resnet18(num_classes=10)
+    conv_case("stem7x7", net.conv1, rnd(2, 3, 32, 32), (3, 64, 7, 2, 3))
+
+    def bn_setup(c):
+        bn = torch.nn.BatchNorm2d(c).double().train()
+        with torch.no_grad():
+            bn.weight.copy_(1 + rnd(c, scale=0.1))
+            bn.bias.copy_(rnd(c, scale=0.1))
+        return bn
+
+    # BatchNorm2d (train) -> ReLU, and BatchNorm2d (+ identity) -> ReLU as at the end of a Bottleneck (model.py:107-113)
+    for tag, with_id in (("bn_relu", False), ("bn_add_relu", True)):
+        bn = bn_setup(64)
+        x = bfr(rnd(2, 64, 12, 12) * 1.5 + 0.25)
+        ident = rnd(2, 64, 12, 12)
+        # "decidable" data, as for top-1 rows: no pre-activation within 0.03 of the ReLU kink (an fp32 / bf16 path may legitimately land
+        # on the other side of it there, and ONE flipped element moves dgamma of its channel by |dy| ~ 1 out of ~17).  Offenders are
+        # pushed away from zero; the batch statistics move a little with them, so repeat until none is left
+        for _ in range(50):
+            with torch.no_grad():
+                z = torch.nn.functional.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.0, 1e-5) + (ident if with_id else 0)
+            near = z.abs() < 0.03
+            if not bool(near.any()):
+                break
+            x = bfr(torch.where(near, x + torch.sign(z) * 0.25, x))
+        assert not bool(near.any())
+        bn.running_mean.zero_(); bn.running_var.fill_(1); bn.num_batches_tracked.zero_()
+        x, ident = x.requires_grad_(True), ident.requires_grad_(True)
+        y = torch.relu(bn(x) + ident) if with_id else torch.relu(bn(x))
+        dy = rnd(*y.shape)
+        y.backward(dy)
+        put(tag, x=x, gamma=bn.weight, beta=bn.bias, ident=ident, y=y, dy=dy, dx=x.grad, dident=ident.grad if with_id else torch.zeros(1),
+            dgamma=bn.weight.grad, dbeta=bn.bias.grad, running_mean=bn.running_mean, running_var=bn.running_var)
+    # the stem's tail exactly as the reference chains it: bn1 -> relu -> maxpool (model.py:150-152, 213-215)
+    bn = bn_setup(64)
+    x = bfr(rnd(2, 64, 16, 16) * 1.5 + 0.25).requires_grad_(True)
+    y = net.maxpool(net.relu(bn(x)))
+    dy = rnd(*y.shape)
+    y.backward(dy)
+    put("stem_tail", x=x, gamma=bn.weight, beta=bn.bias, y=y, dy=dy, dx=x.grad, dgamma=bn.weight.grad, dbeta=bn.bias.grad,
+        running_mean=bn.running_mean, running_var=bn.running_var)
+
+    def block_case(tag, blk, x):
+        blk = blk.double().train()
+        with torch.no_grad():
+            for k, p in blk.named_parameters():
+                if p.ndim == 4:
+                    p.copy_(bfr(p * 1.0))
+                else:
+                    p.copy_(bfr(p + torch.randn(p.shape, generator=g).double() * (0.1 if k.endswith("weight") else 0.1)))
+        x = x.clone().requires_grad_(True)
+        y = blk(x)
+        dy = rnd(*y.shape, scale=0.5)
+        y.backward(dy)
+        put(tag, x=x, dy=dy)
+        out[f"{tag}/y"] = y.detach().numpy().astype(np.float16)       # 2^-11 relative: far inside the 1e-2 bands, half the bytes
+        out[f"{tag}/dx"] = x.grad.detach().numpy().astype(np.float16)
+        for k, p in blk.named_parameters():
+            out[f"{tag}/param/{k}:bf16"] = p.detach().to(torch.bfloat16).view(torch.int16).numpy()
+            assert torch.equal(p.detach(), bfr(p.detach()))
+            out[f"{tag}/grad/{k}"] = p.grad.detach().numpy().astype(np.float32)
+        for k, b in blk.named_buffers():
+            out[f"{tag}/after/{k}"] = b.detach().numpy()
+
+    block_case("bottleneck", ref.Bottleneck(256, 64), rnd(4, 256, 12, 12))   # 576 positions per channel: bias gradients (sums of masked dy) settle
+    ds = torch.nn.Sequential(ref.conv1x1(128, 256, 2), torch.nn.BatchNorm2d(256))     # as _make_layer builds it (model.py:193-197)
+    block_case("bottleneck_ds", ref.Bottleneck(128, 64, stride=2, downsample=ds), rnd(4, 128, 16, 16))
+    block_case("basicblock", ref.BasicBlock(64, 64), rnd(4, 64, 12, 12))
+    np.savez_compressed(os.path.join(GOLD, "resnet_units.npz"), **out)
+    print(f"[resnet units] {len(out)} arrays from the reference's modules (float64) -> tests/golden/resnet_units.npz")
+
+
 def gen_aug():
     """Augmentation / MixUp / CutMix: PARITY UNPINNED (torchvision is absent, the reference holds no fixture) -- these vectors are the
     oracle's own outputs for explicit parameters, committed as DATA so that the restatement cannot drift unnoticed: inputs (uint8
@@ -195,5 +302,7 @@ if __name__ == "__main__":
         gen_vit_full("large_c120_b2", vo.VIT_LARGE, 120, 2, seed=20)
     if what in ("resnet", "all"):
         gen_resnet()
+    if what in ("resnet_units", "resnet", "all"):
+        gen_resnet_units()
     if what in ("aug", "all"):
         gen_aug()

@@ -5,8 +5,9 @@ itself trains, ResNet-152 @256 px with SGD lr 5e-2, TIC/ResNet/train.py:210-255)
   python tools/resnet_bench.py [--arch resnet50|resnet152] [--image 224|256] [--batch 128] [--gpus N] [--graph]
 
 `--gpus N` (N > 1) without a launcher starts its own N ranks exactly as bench.py does (a torch.distributed.run child, started before
-this process touches the GPU).  Data-parallel form: every rank steps its own B images, the flat fp32 gradient buffer behind every
-`.grad` is all-reduced (SUM of 1/world-scaled gradients) in one RCCL call after backward, BatchNorm keeps per-replica statistics.
+this process touches the GPU).  Data-parallel form = the package's own (`dist.BucketedGradSync` on `TicResNet.buckets()`): every rank
+steps its own B images, the six gradient buckets (fc, layer4 .. layer1, stem) are all-reduced on a side stream as the backward
+completes them (SUM of 1/world-scaled gradients), SGD waits for them, BatchNorm keeps per-replica statistics.
 Prints one JSON line on rank 0."""
 import argparse
 import json
@@ -80,9 +81,9 @@ if world > 1:
     dist.init_process_group("nccl", device_id=dev)
 torch.manual_seed(0)
 m = getattr(rm, a.arch)(num_classes=a.classes).to(dev).train()
-if world > 1:
-    for t in list(m.parameters()) + list(m.buffers()):
-        dist.broadcast(t.data, src=0)
+from touhouimageclassification_amd.dist import BucketedGradSync  # noqa: E402
+sync = BucketedGradSync(m, force=bool(os.environ.get("TIC_FORCE_BUCKETS")))   # inactive (no hooks) at world 1 unless forced
+sync.broadcast_parameters()
 opt = torch.optim.SGD(m.parameters(), lr=5e-2)   # TIC/ResNet/train.py:240
 g = torch.Generator().manual_seed(1234 + rank)
 x = torch.randn(a.batch, 3, a.image, a.image, generator=g).to(dev)
@@ -91,9 +92,8 @@ y = torch.randint(0, a.classes, (a.batch,), generator=g).to(dev)
 
 def step(set_to_none=True):
     opt.zero_grad(set_to_none=set_to_none)
-    (torch.nn.functional.cross_entropy(m(x), y) / world).backward()
-    if world > 1:
-        dist.all_reduce(m.__dict__["_flat_grad"])
+    (torch.nn.functional.cross_entropy(m(x), y) * sync.grad_scale).backward()
+    sync.wait()
     opt.step()
 
 

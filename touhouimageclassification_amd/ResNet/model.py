@@ -111,6 +111,7 @@ class TicResNet(nn.Module):
                 if isinstance(m, _Block):
                     nn.init.constant_((m.bn3 if m.kind == "bottleneck" else m.bn2).weight, 0)
         self._anchor = torch.zeros(1, requires_grad=True)
+        self._bucket_hook = None
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn)
@@ -188,21 +189,22 @@ class TicResNet(nn.Module):
             self._call("tic_im2col_bf16", x.data_ptr(), col.data_ptr(), B, H, W, conv.cin, conv.k, conv.k, conv.stride, conv.pad)
         return self._gemm_nt(col, self._pack(conv, 0), M, conv.cout, conv.kp), col, Ho, Wo
 
-    @staticmethod
-    def _bn_scratch(bn: _BN, dev):
-        """2C floats, zero between calls (the kernels accumulate into them and clear them again): allocated once per layer"""
-        s = bn.__dict__.get("_scratch")
+    def _bn_scratch(self, dev):
+        """partial-sum scratch of the BatchNorm column reductions: ONE buffer for every layer of the model (the kernels carry no state
+        in it between calls, launches are stream-ordered).  Sized for the widest layer at the most row splits the library uses:
+        tic_batchnorm_scratch_bytes <= (1 + 512) x 2 x 2048 floats = 8.4 MB; the library checks the size on every call"""
+        s = self.__dict__.get("_bn_scr")
         if s is None or s.device != dev:
-            s = bn.__dict__["_scratch"] = torch.zeros(2 * bn.c, device=dev)
+            s = self.__dict__["_bn_scr"] = torch.empty(513 * 2 * 2048 * 4, dtype=torch.uint8, device=dev)
         return s
 
     def _bn_fwd(self, bn: _BN, x, M, identity, relu, train):
         dev = x.device
         mean, rstd = torch.empty(bn.c, device=dev), torch.empty(bn.c, device=dev)
-        scratch = self._bn_scratch(bn, dev)
+        scratch = self._bn_scratch(dev)
         y = torch.empty_like(x)
         self._call("tic_batchnorm_fwd", x.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                   bn.num_batches_tracked.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(),
+                   bn.num_batches_tracked.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(), scratch.numel(),
                    None if identity is None else identity.data_ptr(), y.data_ptr(), M, bn.c, _EPS, _MOMENTUM, 1 if train else 0, 1 if relu else 0)
         return y, mean, rstd
 
@@ -225,6 +227,17 @@ class TicResNet(nn.Module):
             off = 0
             for p in params:
                 p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        else:   # kept gradients (zero_grad(set_to_none=False), accumulation): every .grad must still BE its range of the flat buffer,
+            off = 0   # because the data-parallel buckets are ranges of it
+            for p in params:
+                want = flat[off:off + p.numel()].view_as(p)
+                if p.grad is None:
+                    want.zero_()
+                    p.grad = want
+                elif p.grad.data_ptr() != want.data_ptr():
+                    want.copy_(p.grad)
+                    p.grad = want
                 off += p.numel()
         convs = [m for m in self.modules() if isinstance(m, _Conv)]
         need = sum(c.cout * c.kp for c in convs)
@@ -271,19 +284,116 @@ class TicResNet(nn.Module):
 
     def _bn_bwd(self, bn: _BN, dy, y_relu, x, mean, rstd, M, dskip=None, skip_accumulate=False, relu_from_x=False):
         dx = torch.empty_like(x)
-        scratch = self._bn_scratch(bn, x.device)
+        scratch = self._bn_scratch(x.device)
         if relu_from_x:   # y = relu(bn(x)), no residual add: the mask is recomputed from x, y is not read
             self._call("tic_batchnorm_bwd_relu", dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(),
-                       scratch.data_ptr(), dx.data_ptr(), self._grad_buf(bn.weight).data_ptr(), self._grad_buf(bn.bias).data_ptr(), M, bn.c)
+                       scratch.data_ptr(), scratch.numel(), dx.data_ptr(), self._grad_buf(bn.weight).data_ptr(), self._grad_buf(bn.bias).data_ptr(), M, bn.c)
             return dx
         self._call("tic_batchnorm_bwd", dy.data_ptr(), None if y_relu is None else y_relu.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                   bn.weight.data_ptr(), scratch.data_ptr(), dx.data_ptr(), None if dskip is None else dskip.data_ptr(), 1 if skip_accumulate else 0,
+                   bn.weight.data_ptr(), scratch.data_ptr(), scratch.numel(), dx.data_ptr(), None if dskip is None else dskip.data_ptr(),
+                   1 if skip_accumulate else 0,
                    self._grad_buf(bn.weight).data_ptr(), self._grad_buf(bn.bias).data_ptr(), M, bn.c)
         return dx
+
+    # ---- data parallelism: gradient buckets = contiguous ranges of the flat gradient buffer, in backward completion order ------
+    _STAGES = ("fc", "layer4", "layer3", "layer2", "layer1", "stem")
+
+    def _stage_modules(self, stage: str):
+        return {"fc": [self.fc], "stem": [self.conv1, self.bn1]}.get(stage) or [getattr(self, stage)]
+
+    def buckets(self):
+        """[(name, start, end)] element ranges of the flat fp32 gradient buffer (parameters() order: stem, layer1..4, fc), listed in
+        the order the backward completes them: fc, layer4 .. layer1, stem.  ResNet-50 (C=120): 0.25 / 15.0 / 7.1 / 1.2 / 0.2 / 0.01 M
+        elements -- the reference has no distributed code; ranks exchange exactly these six ranges per step."""
+        sizes = {}
+        for st in self._STAGES:
+            sizes[st] = sum(p.numel() for m in self._stage_modules(st) for p in m.parameters() if p.requires_grad)
+        order = ("stem", "layer1", "layer2", "layer3", "layer4", "fc")   # parameters() order
+        start, off = {}, 0
+        for st in order:
+            start[st] = off
+            off += sizes[st]
+        return [(st, start[st], start[st] + sizes[st]) for st in self._STAGES]
+
+    def register_bucket_hook(self, hook):
+        """hook(name, grad_slice) -- called during backward as each bucket's gradients are complete (enqueued on the stream)"""
+        self._bucket_hook = hook
+
+    def _fire(self, stage: str):
+        hook = self.__dict__.get("_bucket_hook")
+        if hook is not None:
+            a, b = self.__dict__["_bucket_ranges"][stage]
+            hook(stage, self.__dict__["_flat_grad"][a:b])
+
+    def broadcast_state(self, src: int = 0, group=None):
+        """start-up broadcast: parameters AND BatchNorm buffers (running statistics, counters), coalesced per dtype"""
+        import torch.distributed as dist
+        tensors = [p.data for p in self.parameters()] + [b for b in self.buffers()]
+        for dt in (torch.float32, torch.int64):
+            ts = [t for t in tensors if t.dtype == dt]
+            if not ts:
+                continue
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        # (copy_ bumped the weights' version counters: _refresh_packs re-packs the bf16 operands on the next forward)
 
     # ---- forward / backward -----------------------------------------------------------------------------------------
     def _blocks(self) -> List[_Block]:
         return [b for i in range(1, 5) for b in getattr(self, f"layer{i}")]
+
+    def _block_forward(self, blk: _Block, h, B: int, Hc: int, Wc: int, train: bool):
+        """one residual block (TIC/ResNet/model.py:47-63 BasicBlock, :95-115 Bottleneck) on h [B*Hc*Wc, Cin] bf16 NHWC ->
+        (out, Ho, Wo, record for _block_backward)"""
+        rec = {"in": h, "H": Hc, "W": Wc}
+        convs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)] + ([(blk.conv3, blk.bn3)] if blk.kind == "bottleneck" else [])
+        if blk.downsample is not None:
+            cd, cold, Hd, Wd = self._conv_fwd(blk.downsample[0], h, B, Hc, Wc)
+            identity, md, rd = self._bn_fwd(blk.downsample[1], cd, B * Hd * Wd, None, False, train)
+            rec["ds"] = (cold, cd, md, rd)
+        else:
+            identity = h
+        t, Ht, Wt = h, Hc, Wc
+        steps = []
+        for i, (cv, bn) in enumerate(convs):
+            last = i == len(convs) - 1
+            c, col, Ho, Wo = self._conv_fwd(cv, t, B, Ht, Wt)
+            y, m, r = self._bn_fwd(bn, c, B * Ho * Wo, identity if last else None, True, train)
+            steps.append((col, c, y, m, r, Ht, Wt))
+            t, Ht, Wt = y, Ho, Wo
+        rec["steps"] = steps
+        return t, Ht, Wt, rec
+
+    def _block_backward(self, blk: _Block, rec, dh, B: int):
+        """gradient of one block: dh = d(loss)/d(block output) [M, Cout] bf16 -> d(loss)/d(block input); parameter gradients accumulate"""
+        convs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)] + ([(blk.conv3, blk.bn3)] if blk.kind == "bottleneck" else [])
+        steps = rec["steps"]
+        dident = torch.empty_like(dh)   # gradient of the identity / downsample branch = masked block-output gradient
+        d = dh
+        folded = False
+        for i in reversed(range(len(convs))):
+            cv, bn = convs[i]
+            col, c, y, m, r, Hi, Wi = steps[i]
+            last = i == len(convs) - 1
+            if last:
+                d = self._bn_bwd(bn, d, y, c, m, r, c.shape[0], dskip=dident)
+            else:
+                d = self._bn_bwd(bn, d, None, c, m, r, c.shape[0], relu_from_x=True)
+            # the block's first conv: when it is a 1x1 / stride-1 GEMM and the identity branch has no downsample, its input
+            # gradient is added onto the identity-branch gradient by the GEMM epilogue (no separate add pass)
+            fold = i == 0 and blk.downsample is None and cv.k == 1 and cv.stride == 1
+            d = self._conv_bwd(cv, d, col, B, Hi, Wi, need_dx=True, dx_accumulate_into=dident if fold else None)
+            folded = fold
+        if blk.downsample is not None:
+            cold, cd, md, rd = rec["ds"]
+            dd = self._bn_bwd(blk.downsample[1], dident, None, cd, md, rd, cd.shape[0])
+            self._conv_bwd(blk.downsample[0], dd, cold, B, rec["H"], rec["W"], need_dx=True, dx_accumulate_into=d)
+        elif not folded:
+            self._call("tic_add_bf16", d.data_ptr(), dident.data_ptr(), d.numel())
+        return d
 
     def _forward_impl(self, x: torch.Tensor, train: bool, record: bool):
         self.backend.check_tensor(x)
@@ -305,30 +415,14 @@ class TicResNet(nn.Module):
         pidx = torch.empty(B * Hp * Wp, 64, dtype=torch.uint8, device=dev) if record else None
         bn = self.bn1
         self._call("tic_bn_relu_maxpool_fwd", c0.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                   bn.num_batches_tracked.data_ptr(), m0.data_ptr(), r0.data_ptr(), self._bn_scratch(bn, dev).data_ptr(), h.data_ptr(),
+                   bn.num_batches_tracked.data_ptr(), m0.data_ptr(), r0.data_ptr(), self._bn_scratch(dev).data_ptr(),
+                   self._bn_scratch(dev).numel(), h.data_ptr(),
                    None if pidx is None else pidx.data_ptr(), B, H1, W1, 64, _EPS, _MOMENTUM, 1 if train else 0)
         tape["stem"] = (col0, c0, m0, r0, H, W, H1, W1, pidx)
         Hc, Wc = Hp, Wp
         for blk in self._blocks():
-            rec = {"in": h, "H": Hc, "W": Wc}
-            convs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)] + ([(blk.conv3, blk.bn3)] if blk.kind == "bottleneck" else [])
-            if blk.downsample is not None:
-                cd, cold, Hd, Wd = self._conv_fwd(blk.downsample[0], h, B, Hc, Wc)
-                identity, md, rd = self._bn_fwd(blk.downsample[1], cd, B * Hd * Wd, None, False, train)
-                rec["ds"] = (cold, cd, md, rd)
-            else:
-                identity = h
-            t, Ht, Wt = h, Hc, Wc
-            steps = []
-            for i, (cv, bn) in enumerate(convs):
-                last = i == len(convs) - 1
-                c, col, Ho, Wo = self._conv_fwd(cv, t, B, Ht, Wt)
-                y, m, r = self._bn_fwd(bn, c, B * Ho * Wo, identity if last else None, True, train)
-                steps.append((col, c, y, m, r, Ht, Wt))
-                t, Ht, Wt = y, Ho, Wo
-            rec["steps"] = steps
+            h, Hc, Wc, rec = self._block_forward(blk, h, B, Hc, Wc, train)
             tape["blocks"].append(rec)
-            h, Hc, Wc = t, Ht, Wt
         feat = self.fc.weight.shape[1]
         z = torch.empty(B, feat, dtype=torch.bfloat16, device=x.device)
         self._call("tic_avgpool_fwd", h.data_ptr(), z.data_ptr(), B, Hc * Wc, feat)
@@ -353,43 +447,27 @@ class TicResNet(nn.Module):
                    self._grad_buf(self.fc.bias).data_ptr(), B, self.num_classes, feat)
         dh = torch.empty(B * Hc * Wc, feat, dtype=torch.bfloat16, device=dev)
         self._call("tic_avgpool_bwd", dz.data_ptr(), dh.data_ptr(), B, Hc * Wc, feat)
-        for blk, rec in zip(reversed(self._blocks()), reversed(tape["blocks"])):
-            convs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2)] + ([(blk.conv3, blk.bn3)] if blk.kind == "bottleneck" else [])
-            steps = rec["steps"]
-            dident = torch.empty_like(dh)   # gradient of the identity / downsample branch = masked block-output gradient
-            d = dh
-            for i in reversed(range(len(convs))):
-                cv, bn = convs[i]
-                col, c, y, m, r, Hi, Wi = steps[i]
-                last = i == len(convs) - 1
-                if last:
-                    d = self._bn_bwd(bn, d, y, c, m, r, c.shape[0], dskip=dident)
-                else:
-                    d = self._bn_bwd(bn, d, None, c, m, r, c.shape[0], relu_from_x=True)
-                # the block's first conv: when it is a 1x1 / stride-1 GEMM and the identity branch has no downsample, its input
-                # gradient is added onto the identity-branch gradient by the GEMM epilogue (no separate add pass)
-                fold = i == 0 and blk.downsample is None and cv.k == 1 and cv.stride == 1
-                d = self._conv_bwd(cv, d, col, B, Hi, Wi, need_dx=True, dx_accumulate_into=dident if fold else None)
-                folded = fold
-            if blk.downsample is not None:
-                cold, cd, md, rd = rec["ds"]
-                dd = self._bn_bwd(blk.downsample[1], dident, None, cd, md, rd, cd.shape[0])
-                self._conv_bwd(blk.downsample[0], dd, cold, B, rec["H"], rec["W"], need_dx=True, dx_accumulate_into=d)
-            elif not folded:
-                self._call("tic_add_bf16", d.data_ptr(), dident.data_ptr(), d.numel())
-            dh = d
+        self.__dict__["_bucket_ranges"] = {n: (a, b) for n, a, b in self.buckets()}
+        self._fire("fc")
+        stage_of = [(f"layer{i}", b) for i in range(1, 5) for b in getattr(self, f"layer{i}")]
+        for bi, (blk, rec) in reversed(list(enumerate(zip(self._blocks(), tape["blocks"])))):
+            dh = self._block_backward(blk, rec, dh, B)
+            if bi == 0 or stage_of[bi - 1][0] != stage_of[bi][0]:   # first block of its stage: the stage's gradients are complete
+                self._fold_weight_grads(dev, stage_of[bi][0])
+                self._fire(stage_of[bi][0])
         col0, c0, m0, r0, H, W, H1, W1, pidx = tape["stem"]
         da0 = torch.empty_like(c0)   # gradient of the (never stored) relu(bn1(c0)): from the pooled gradient and the argmax positions
         self._call("tic_maxpool3x3s2_bwd_idx", pidx.data_ptr(), dh.data_ptr(), da0.data_ptr(), B, H1, W1, 64)
         dc0 = self._bn_bwd(self.bn1, da0, None, c0, m0, r0, c0.shape[0], relu_from_x=True)
         self._conv_bwd(self.conv1, dc0, col0, B, H, W, need_dx=False)
-        self._fold_weight_grads(dev)
+        self._fold_weight_grads(dev, "stem")
+        self._fire("stem")
 
-    def _fold_weight_grads(self, dev):
-        """grad (OIHW) += dw scratch ([Cout, Kp], tap-major) for every conv in one launch"""
-        convs = [m for m in self.modules() if isinstance(m, _Conv)]
+    def _fold_weight_grads(self, dev, stage: str):
+        """grad (OIHW) += dw scratch ([Cout, Kp], tap-major) for every conv of one stage in one launch (a stage = one gradient bucket)"""
+        convs = [m for top in self._stage_modules(stage) for m in top.modules() if isinstance(m, _Conv)]
         ptrs = (tuple(self._grad_buf(c.weight).data_ptr() for c in convs), tuple(c.__dict__["_dw_view"].data_ptr() for c in convs), dev)
-        st = self.__dict__.setdefault("_fold_state", {})
+        st = self.__dict__.setdefault("_fold_state", {}).setdefault(stage, {})
         if st.get("ptrs") != ptrs:
             descs = [struct.pack("<QQiiii", c.__dict__["_dw_view"].data_ptr(), self._grad_buf(c.weight).data_ptr(), c.cout, c.cin, c.k, c.k) for c in convs]
             st["n"] = len(descs)

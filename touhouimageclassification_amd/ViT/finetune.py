@@ -24,6 +24,7 @@ import sys
 from typing import List, Optional, Sequence, Tuple
 
 import torch
+import torch.distributed as dist
 from torch.utils.data import DataLoader, random_split
 
 
@@ -69,18 +70,27 @@ def _logits_of(outputs):
 
 
 def train_step(model, data, optimizer, criterion, scaler=None, scheduler=None) -> float:
-    """One optimisation step; returns the loss as a Python float (this is the reference's per-step host sync)."""
+    """One optimisation step; returns the loss as a Python float (this is the reference's per-step host sync).
+    Data parallel (one process per GPU; `train_model` attaches `model._dp_sync`): the batch is this rank's shard, the loss
+    gradient is scaled by 1 / world so that the per-bucket SUM all-reduce fired during backward yields the global-batch mean,
+    and the optimizer waits for the buckets.  The returned loss is this rank's."""
     model.train()
     optimizer.zero_grad()
     dev = _device_of(model)
+    sync = getattr(model, "_dp_sync", None)
     inputs, labels = (torch.as_tensor(t).to(dev, non_blocking=True) for t in data)
     loss = criterion(_logits_of(model(_prepare(model, inputs))), labels)
+    back = loss if sync is None else loss * sync.grad_scale
     if scaler is not None and getattr(scaler, "is_enabled", lambda: False)():
-        scaler.scale(loss).backward()
+        scaler.scale(back).backward()
+        if sync is not None:
+            sync.wait()
         scaler.step(optimizer)
         scaler.update()
     else:
-        loss.backward()
+        back.backward()
+        if sync is not None:
+            sync.wait()
         optimizer.step()
     if scheduler:
         scheduler.step()
@@ -166,27 +176,54 @@ def train_model(model: torch.nn.Module, dataset, optimizer, scheduler, criterion
     torch.manual_seed(0)   # split consistency across runs
     train_set, val_set = random_split(dataset, [len(dataset) - n_val, n_val])
     pin = _device_of(model).type == "cuda"
-    train_loader = DataLoader(train_set, batch_size=batch_size, shuffle=True, pin_memory=pin, num_workers=num_workers)
-    val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, pin_memory=pin, num_workers=num_workers)
+    # data parallel (absent from the reference: single process, finetune.py:313): `batch_size` is PER RANK; every rank trains on its
+    # DistributedSampler shard (equal lengths: each step has a collective), validates on an unpadded shard (every sample once),
+    # the epoch metrics are all-reduced, rank 0 writes the checkpoints and the log lines
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+    train_sampler = val_sampler = None
+    if world > 1:
+        from ..dist import BucketedGradSync, UnpaddedShardSampler
+        if not hasattr(model, "register_bucket_hook"):
+            raise TypeError("data-parallel train_model needs a TIC model (gradient buckets)")
+        model._dp_sync = BucketedGradSync(model)
+        model._dp_sync.broadcast_parameters()
+        train_sampler = torch.utils.data.distributed.DistributedSampler(train_set, num_replicas=world, rank=rank, shuffle=True, seed=0)
+        val_sampler = UnpaddedShardSampler(val_set, world, rank)
+    train_loader = DataLoader(train_set, batch_size=batch_size, shuffle=train_sampler is None, sampler=train_sampler, pin_memory=pin,
+                              num_workers=num_workers)
+    val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, sampler=val_sampler, pin_memory=pin, num_workers=num_workers)
+
+    def reduce(*vals):
+        if world == 1:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64, device=_device_of(model))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return tuple(t.tolist())
 
     def run_train(epoch: int) -> float:
         if scheduler and scheduler_per_epoch:
             logger.info(f"LR for epoch {epoch + 1}: {scheduler.get_last_lr()[0]:.6e}")
-        running = 0.0
+        if train_sampler is not None:
+            train_sampler.set_epoch(epoch)
+        running, steps = 0.0, 0
         for i, batch in enumerate(train_loader):
             loss = train_step(model, batch, optimizer, criterion, scaler, None if scheduler_per_epoch else scheduler)
             running += _nan_guard(loss, running, i, "training", epoch, logger)
-        return running / len(train_loader) if len(train_loader) else 0.0
+            steps += 1
+        running, steps = reduce(running, steps)
+        return running / steps if steps else 0.0
 
     def run_val(epoch: int) -> Tuple[float, float]:
         optimizer.zero_grad(set_to_none=True)
-        running, correct, total = 0.0, 0, 0
+        running, correct, total, steps = 0.0, 0, 0, 0
         for i, batch in enumerate(val_loader):
             loss, c = validate_step(model, batch, criterion)
             running += _nan_guard(loss, running, i, "validation", epoch, logger)
             correct += c
             total += len(batch[1])
-        return (running / len(val_loader) if len(val_loader) else 0.0), (100.0 * correct / total if total else 0.0)
+            steps += 1
+        running, correct, total, steps = reduce(running, correct, total, steps)
+        return (running / steps if steps else 0.0), (100.0 * correct / total if total else 0.0)
 
     if start_epoch:
         logger.info(f"Validating model from loaded checkpoint (Epoch {start_epoch}) before resuming training...")
@@ -202,9 +239,10 @@ def train_model(model: torch.nn.Module, dataset, optimizer, scheduler, criterion
         if scheduler and scheduler_per_epoch:
             state += (scheduler.state_dict(),)
         path = save_path.format(epoch=epoch + 1)
-        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        torch.save(state, path)
-        logger.info(f"Checkpoint saved to {path}")
+        if rank == 0:   # replicas are identical
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            torch.save(state, path)
+            logger.info(f"Checkpoint saved to {path}")
         logger.info(f"Epoch [{epoch + 1}/{num_epochs}], Training Loss: {tl:.4f}, Validation Loss: {vl:.4f}, Accuracy: {acc:.2f}%")
         if early_exit(timeline, max_tolerant_epoch, logger):
             break

@@ -181,6 +181,16 @@ class TicViTForImageClassification(nn.Module):
         """hook(name, grad_slice) -- called during backward as each gradient bucket completes (DP)."""
         self._bucket_hook = hook
 
+    def buckets(self):
+        """[(name, start, end)] ranges of the flat gradient buffer in backward completion order (head, layer L-1 .. 0, embed)"""
+        return self._engine.buckets()
+
+    def broadcast_state(self, src: int = 0, group=None):
+        """start-up broadcast of the flat fp32 master weights (one collective); the bf16 operand copies follow"""
+        import torch.distributed as dist
+        dist.broadcast(self._engine.params, src=src, group=group)
+        self._engine.mark_weights_dirty()
+
     def forward(self, pixel_values: torch.Tensor, labels: Optional[torch.Tensor] = None, **kwargs):
         c = self.config
         if pixel_values.dim() != 4 or pixel_values.shape[1] != c.num_channels:

@@ -30,7 +30,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..aug import CutMixOrMixUp, GpuAugment, preset_name
-from ..dist import BucketedGradSync
+from ..dist import BucketedGradSync, UnpaddedShardSampler
 from ..optim import FusedAdamW
 from .model import TicViTForImageClassification, ViT
 
@@ -171,9 +171,11 @@ class AugmentedDataset:
         """Under torch.distributed every rank iterates its own 1/world shard of `ds` (DistributedSampler: same permutation on
         every rank, seeded by the epoch the Trainer sets, rank-strided slices); the reference is single-process (ntrain.py:240)."""
         sampler = None
-        if _world() > 1:
-            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=_world(), rank=_rank(), shuffle=shuffle, seed=42)
+        if _world() > 1 and shuffle:   # training: equal shard lengths (every step has a collective), a new permutation per epoch
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=_world(), rank=_rank(), shuffle=True, seed=42)
             self._samplers.append(sampler)
+        elif _world() > 1:            # validation / test: every sample exactly once over the ranks, no padding (metrics = the single-process ones)
+            sampler = UnpaddedShardSampler(ds, _world(), _rank())
         return torch.utils.data.DataLoader(ds, batch_size=self.batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
                                            num_workers=self.num_workers, pin_memory=torch.cuda.is_available())
 

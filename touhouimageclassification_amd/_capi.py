@@ -84,12 +84,13 @@ SIGNATURES = {
     "tic_nchw_to_nhwc_bf16": ([P, P, I, I, I, I, P], I),
     "tic_im2col_bf16": ([P, P, I, I, I, I, I, I, I, I, P], I),
     "tic_col2im_bf16": ([P, P, I, I, I, I, I, I, I, I, I, P], I),
-    "tic_batchnorm_fwd": ([P, P, P, P, P, P, P, P, P, P, P, L, I, F, F, I, I, P], I),
-    "tic_batchnorm_bwd": ([P, P, P, P, P, P, P, P, P, I, P, P, L, I, P], I),
-    "tic_batchnorm_bwd_relu": ([P, P, P, P, P, P, P, P, P, P, L, I, P], I),
+    "tic_batchnorm_scratch_bytes": ([L, I], SZ),
+    "tic_batchnorm_fwd": ([P, P, P, P, P, P, P, P, P, SZ, P, P, L, I, F, F, I, I, P], I),
+    "tic_batchnorm_bwd": ([P, P, P, P, P, P, P, SZ, P, P, I, P, P, L, I, P], I),
+    "tic_batchnorm_bwd_relu": ([P, P, P, P, P, P, P, SZ, P, P, P, L, I, P], I),
     "tic_maxpool3x3s2_fwd": ([P, P, I, I, I, I, P], I),
     "tic_maxpool3x3s2_bwd": ([P, P, P, P, I, I, I, I, P], I),
-    "tic_bn_relu_maxpool_fwd": ([P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, F, I, P], I),
+    "tic_bn_relu_maxpool_fwd": ([P, P, P, P, P, P, P, P, P, SZ, P, P, I, I, I, I, F, F, I, P], I),
     "tic_maxpool3x3s2_fwd_idx": ([P, P, P, I, I, I, I, P], I),
     "tic_maxpool3x3s2_bwd_idx": ([P, P, P, I, I, I, I, P], I),
     "tic_avgpool_fwd": ([P, P, I, I, I, P], I),

@@ -244,9 +244,16 @@ __global__ void __launch_bounds__(256) col2im_kernel(const bf16_t* __restrict__ 
 }
 
 // ---- BatchNorm (train mode) over [M, C] bf16, C % 8 == 0 ------------------------------------------------
-// sums[0..C) += sum_m x, sums[C..2C) += sum_m x^2.  A block covers cpb = min(C/8, 32) 8-channel chunks with R = 256/cpb
-// row lanes (so narrow layers -- C = 64 -- still use every thread); grid (ceil(C/256), row_splits); LDS 2*2048 floats.
-__global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums, long M, int C) {
+// Column reductions WITHOUT atomics, so that they are bit-reproducible: row split k (blockIdx.y) STORES its partial sums
+// part[k][0..C) = sum_m x, part[k][C..2C) = sum_m x^2 over its rows, and the consuming kernel adds the splits up in a fixed order
+// (bn_sum_parts).  Why it matters: a BatchNorm statistic that moves by one fp32 ulp with the order of the adds moves a few bf16
+// roundings of the normalised activation, and three or four layers later the whole activation carries an independent realisation
+// of the bf16 storage noise -- two runs of the SAME step then differ by as much as either differs from exact arithmetic (measured on
+// the atomics form: 13 % relative L2 between the gradients of two identical ResNet-18 steps).  With fixed-order sums the forward and
+// the activation gradients are bit-identical run to run; only the weight-gradient accumulations (outputs, nothing downstream) keep
+// an order dependence of a few fp32 ulps.  A block covers cpb = min(C/8, 32) 8-channel chunks with R = 256/cpb row lanes (so narrow
+// layers -- C = 64 -- still use every thread); grid (ceil(C/256), row_splits); LDS 2*2048 floats.
+__global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, long M, int C) {
     const int cpb = (C / 8) < 32 ? (C / 8) : 32, R = 256 / cpb;
     const int tx = TIC_TID % cpb, ty = TIC_TID / cpb;
     const int c0 = TIC_BID_X * 256 + tx * 8;
@@ -292,33 +299,68 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const bf16_t* __restrict_
             a += lds_ldf((uint32_t)(k * cw + TIC_TID) * 4u);
             b += lds_ldf((uint32_t)(2048 + k * cw + TIC_TID) * 4u);
         }
-        atomic_addf(sums + TIC_BID_X * 256 + TIC_TID, a);
-        atomic_addf(sums + C + TIC_BID_X * 256 + TIC_TID, b);
+        float* dst = part + (size_t)TIC_BID_Y * 2 * C;
+        dst[TIC_BID_X * 256 + TIC_TID] = a;
+        dst[C + TIC_BID_X * 256 + TIC_TID] = b;
     }
 }
-// train: mean/rstd from the batch sums, running stats updated (unbiased var), counter += 1; eval: from running stats
-// (the sums are consumed here and left ZERO for the next launch that accumulates into them: no memset per layer)
-__global__ void __launch_bounds__(256) bn_finalize_kernel(float* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd,
+// fixed-order sum of the row splits' partial sums for the block's BN_SUM_CH = 16 channels: thread (l, ch) = (tid / 16, tid % 16) adds
+// splits l, l + 16, l + 32, ... -- eight independent running sums (eight loads in flight: the loop is a chain of L2 round trips, 512
+// splits took 64 of them with one sum per thread), combined in a fixed order -- then lane 0 adds the sixteen lane sums in lane order.
+// Valid in threads tid < 16 (channel c = blockIdx.x * 16 + tid, caller checks c < C).  LDS: 2 * 256 floats.
+#define BN_SUM_CH 16
+TIC_DEV void bn_sum_parts(const float* __restrict__ part, int nsplit, int C, float& a, float& b) {
+    const int ch = TIC_TID % BN_SUM_CH, l = TIC_TID / BN_SUM_CH, c = TIC_BID_X * BN_SUM_CH + ch;
+    constexpr int L = 256 / BN_SUM_CH;
+    float sa[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c < C) {
+        int k = l;
+        for (; k + 7 * L < nsplit; k += 8 * L) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sa[u] += part[(size_t)(k + u * L) * 2 * C + c];
+                sb[u] += part[(size_t)(k + u * L) * 2 * C + C + c];
+            }
+        }
+        for (int u = 0; k < nsplit; k += L, ++u) {
+            sa[u] += part[(size_t)k * 2 * C + c];
+            sb[u] += part[(size_t)k * 2 * C + C + c];
+        }
+    }
+    a = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
+    b = ((sb[0] + sb[1]) + (sb[2] + sb[3])) + ((sb[4] + sb[5]) + (sb[6] + sb[7]));
+    lds_stf((uint32_t)TIC_TID * 4u, a);
+    lds_stf((uint32_t)(256 + TIC_TID) * 4u, b);
+    block_sync();
+    if (l == 0)
+        for (int k = 1; k < L; ++k) {
+            a += lds_ldf((uint32_t)(k * BN_SUM_CH + ch) * 4u);
+            b += lds_ldf((uint32_t)(256 + k * BN_SUM_CH + ch) * 4u);
+        }
+}
+// train: mean/rstd from the batch sums (the row splits' partials added up in a fixed order), running stats updated (unbiased var),
+// counter += 1; eval (nsplit = 0): from running stats.  Grid ceil(C / BN_SUM_CH).
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ mean, float* __restrict__ rstd,
                                                            float* running_mean, float* running_var, long long* num_batches, long M, int C,
                                                            float eps, float momentum, int train) {
-    const int c = TIC_BID_X * 256 + TIC_TID;
-    if (c < C) {
+    float sa, sb;
+    bn_sum_parts(part, train ? nsplit : 0, C, sa, sb);
+    const int c = TIC_BID_X * BN_SUM_CH + TIC_TID;
+    if (TIC_TID < BN_SUM_CH && c < C) {
         if (train) {
-            const float mu = sums[c] / (float)M;
-            float var = sums[C + c] / (float)M - mu * mu;
+            const float mu = sa / (float)M;
+            float var = sb / (float)M - mu * mu;
             if (var < 0.f) var = 0.f;
             mean[c] = mu;
             rstd[c] = 1.0f / sqrtf(var + eps);
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)M / (float)(M > 1 ? M - 1 : 1));
-            sums[c] = 0.f;
-            sums[C + c] = 0.f;
         } else {
             mean[c] = running_mean[c];
             rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
         }
     }
-    if (train && num_batches && c == 0) *num_batches += 1;
+    if (train && num_batches && TIC_BID_X == 0 && TIC_TID == 0) *num_batches += 1;
 }
 // y = [relu]( (x - mean) rstd gamma + beta [+ identity] )
 __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -350,13 +392,14 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const bf16_t* __restrict_
         *reinterpret_cast<u32x4*>(y + off) = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
     }
 }
-// dz = dy * [y > 0] (if y given);  red[0..C) += sum dz ; red[C..2C) += sum dz * xhat   (same thread mapping as bn_stats)
+// dz = dy * [y > 0] (if y given);  part[k][0..C) = sum dz ; part[k][C..2C) = sum dz * xhat over row split k (same thread mapping and
+// the same atomics-free partial sums as bn_stats)
 // mask_from_x (instead of y): the layer was y = relu(bn(x)) WITHOUT a residual add, so the mask is recomputed from x exactly as
 // bn_apply_kernel formed it (same fp32 expression, same bf16 rounding) and y is not read at all.  gamma_m / beta_m are ALWAYS valid
 // pointers (the host passes gamma for both when the mask is not wanted): a null test per channel in the prologue turned its
 // vector loads into 8 dependent load-wait-branch rounds (+60 us per launch)
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, const bf16_t* y, const bf16_t* __restrict__ x,
-                                                             const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ red, long M, int C,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ part, long M, int C,
                                                              const float* __restrict__ gamma_m, const float* __restrict__ beta_m, int mask_from_x) {
     const int cpb = (C / 8) < 32 ? (C / 8) : 32, R = 256 / cpb;
     const int tx = TIC_TID % cpb, ty = TIC_TID / cpb;
@@ -417,8 +460,23 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const bf16_t* __rest
             a += lds_ldf((uint32_t)(k * cw + TIC_TID) * 4u);
             b += lds_ldf((uint32_t)(2048 + k * cw + TIC_TID) * 4u);
         }
-        atomic_addf(red + TIC_BID_X * 256 + TIC_TID, a);
-        atomic_addf(red + C + TIC_BID_X * 256 + TIC_TID, b);
+        float* dst = part + (size_t)TIC_BID_Y * 2 * C;
+        dst[TIC_BID_X * 256 + TIC_TID] = a;
+        dst[C + TIC_BID_X * 256 + TIC_TID] = b;
+    }
+}
+// red[0..2C) = the splits' partial sums added up in a fixed order (what bn_bwd_apply reads);  dbeta += red[0..C), dgamma += red[C..2C).
+// Grid ceil(C / BN_SUM_CH).
+__global__ void __launch_bounds__(256) bn_param_grad_kernel(const float* __restrict__ part, int nsplit, float* __restrict__ red, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int C) {
+    float sa, sb;
+    bn_sum_parts(part, nsplit, C, sa, sb);
+    const int c = TIC_BID_X * BN_SUM_CH + TIC_TID;
+    if (TIC_TID < BN_SUM_CH && c < C) {
+        red[c] = sa;
+        red[C + c] = sb;
+        dbeta[c] += sa;
+        dgamma[c] += sb;
     }
 }
 // dx = gamma rstd (dz - dbeta/M - xhat dgamma/M);  dskip (optional) (+)= dz  (the identity-path gradient)

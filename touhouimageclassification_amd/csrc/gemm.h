@@ -48,6 +48,8 @@ struct GemmNtParams {
     float* slab;
     unsigned* flags;
     unsigned epoch;          // value a flag takes in THIS launch (the host counts launches: flags never need clearing)
+    unsigned* err;           // host-mapped error word: a consumer whose flag poll ran out stores 0xDEADxxxx there (tic_prims.h flag_wait)
+    int fault;               // test builds only (tic_set_option "nt_fault"): part 0 of every tile never publishes its flag
 #ifdef TIC_MEASURE
     unsigned long long* stamps;   // measurement build only: [grid][8] s_memrealtime stamps of the 256x256 kernel's stages, or nullptr
 #endif
@@ -310,11 +312,11 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
                 for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(dst + (size_t)(i * 4 + j) * 256 * 4) = acc[i][j];
             wait_vmcnt0();
             block_sync();
-            if (tid == 0) flag_publish(p.flags + tile_id * 4 + part, p.epoch);
+            if (tid == 0 && !(p.fault && part == 0)) flag_publish(p.flags + tile_id * 4 + part, p.epoch);
             return;
         }
         for (int q = 0; q < nparts - 1; ++q) {
-            if (tid == 0) flag_wait(p.flags + tile_id * 4 + q, p.epoch);
+            if (tid == 0) flag_wait(p.flags + tile_id * 4 + q, p.epoch, p.err);
             block_sync();
             const float* src = p.slab + ((size_t)(tile_id * (nparts - 1) + q) * 16 * 256 + tid) * 4;
 #pragma unroll

@@ -477,11 +477,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
                 for (int r = 0; r < 8; ++r) slab[(size_t)(g * 8 + r) * 512] = acc[r >> 2][g >> 1][r & 3][g & 1];
             wait_vmcnt0();
             g256_barrier();
-            if (tide == 0) flag_publish(p.flags + tile_id * 4 + part, p.epoch);
+            if (tide == 0 && !(p.fault && part == 0)) flag_publish(p.flags + tile_id * 4 + part, p.epoch);
             return;
         }
         for (int q = 0; q < nparts - 1; ++q) {   // block-uniform trip count
-            if (tide == 0) flag_wait(p.flags + tile_id * 4 + q, p.epoch);
+            if (tide == 0) flag_wait(p.flags + tile_id * 4 + q, p.epoch, p.err);
             g256_barrier();
             const f32x4* slab = reinterpret_cast<const f32x4*>(p.slab) + ((size_t)tile_id * (nparts - 1) + q) * slab_f4 + tide;
 #pragma unroll

@@ -14,7 +14,6 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "gemm256.h"
-#include "gemm256p.h"
 #include "gemm_tn256.h"
 #include "moe.h"
 #include "norm.h"
@@ -38,9 +37,19 @@ static int tic_fail(int code, const char* fmt, ...) {
         if (rc_ != TIC_OK) return rc_; \
     } while (0)
 
+// device -> host error word of the split-K hand-offs (tic_prims.h flag_wait): 64 bytes of pinned, device-mapped HOST memory, made once
+// when a split-K scratch is first registered -- the one allocation this library makes, and not device memory.  Sticky: once set, every
+// call fails with TIC_ELAUNCH until tic_gemm_nt_scratch() registers a scratch again (the caller re-zeroes the flags with it).
+static unsigned* g_err_host = nullptr;
+static unsigned* g_err_dev = nullptr;
 static int tic_after_launch(const char* what) {
     const char* e = TIC_RT_LAST_ERROR();
     if (e) return tic_fail(TIC_ELAUNCH, "%s: %s", what, e);
+    if (g_err_host) {
+        const unsigned w = *(volatile unsigned*)g_err_host;
+        if (w) return tic_fail(TIC_ELAUNCH, "%s: a split-K GEMM consumer timed out waiting for its producer's flag (code 0x%08x): the activations / "
+                               "gradients written since are invalid; re-register the scratch (tic_gemm_nt_scratch) after zeroing its flag words", what, w);
+    }
     return TIC_OK;
 }
 
@@ -78,12 +87,7 @@ static int g_opt_tn_streamk_min_steps = 128;   // grouped dW: fewest 64-row step
 static int g_opt_ln_bwd_blocks = 512;    // LayerNorm backward: most blocks per launch
 static int g_opt_ln_bwd_rows = 2;        // LayerNorm backward: fewest rows per wave (bounds the number of dgamma / dbeta atomic rows)
 static int g_opt_gemm_big_tiles = 128;   // fewest 256x256 tiles for which the 256x256 NT kernel is chosen (gemm_tile = 0)
-static int g_opt_gemm_split = -1;       // split-K form of the 256x256 NT kernel: -1 auto, 0 / 1 never, 2 / 4 forced where legal (tests)
-static int g_opt_gemm_persist = 0;      // 1: persistent 256x256 NT kernel (gemm256p.h) where a launch has more tiles than workgroups.  OFF by default:
-                                        // bit-identical, but 1.9 % SLOWER on the step (tools/ab_step.py gemm_persist 0 1: 130.3 vs 132.8 ms) -- what it
-                                        // removes (2.0 us prologue + 1.6 us between workgroups per tile) was the cover of the previous tile's store
-                                        // drain, which now runs into the next K loop instead (profiles/r02_tile_timeline_persistent.log)
-static int g_opt_gemm_pgrid = 256;      // its grid: one workgroup per CU (tests shrink it to force several tiles per workgroup)
+static int g_opt_gemm_split = -1;       // split-K form of the 128x128 NT kernel (and, measurement build, the 256x256 one): -1 auto, 0 / 1 never, 2 / 4 forced where legal
 static int g_opt_gemm_stagger_mask = 0x7f;   // bit e: apply "gemm_stagger" to epilogue e
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
@@ -91,101 +95,66 @@ static int g_opt_tn_block = -1;   // tile-walk block width of the grouped dW lau
 static int g_opt_tn_mfma = 0;     // MFMA shape of the grouped dW stream-K launch: 0 auto (16x16x32 from 512 M steps per tile on: -1.7 % at M = 65 404,
                                   // but +2..5 % at M = 12 608, tools/dw_ab.py tn_mfma 16 32), 16, 32
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
+#if defined(TIC_SIM) || defined(TIC_MEASURE)
+static int g_opt_nt_fault = 0;   // test builds: part 0 of every split tile withholds its flag (exercises the timeout report of flag_wait)
+#endif
+// The SIX knobs of the product library select between numerically equivalent routes, so that the parity tests can force each one
+// (include/tic_hip.h documents them).  They are plain process-wide ints read at launch time: set them while no other host thread is
+// inside a tic_* call.  Everything else that was ever A/B-ed lives in the measurement build only (-DTIC_MEASURE, libtic_hip_dbg.so).
 extern "C" int tic_set_option(const char* name, int value) {
-    if (name && !strcmp(name, "ln_blocks") && value >= 64 && value <= 65536) {
-        g_opt_ln_blocks = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "attn_fwd_waves") && (value == 4 || value == 8)) {
-        g_opt_attn_fwd_waves = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "tn_main_bias") && value >= 0 && value <= 64) {
-        g_opt_tn_main_bias = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "gemm_gm") && value >= 1 && value <= 256) {
-        g_opt_gemm_gm = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
-        g_opt_nt = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "tn_slab") && (value == 0 || value == 1)) {
-        g_opt_tn_slab = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "tn_split_wgs") && value >= 64 && value <= 8192) {
-        g_opt_tn_split_wgs = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "tn_parts") && value >= -1 && value <= 8) {
-        g_opt_tn_parts = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "tn_streamk_min_steps") && value >= 1 && value <= (1 << 20)) {
-        g_opt_tn_streamk_min_steps = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "ln_bwd_blocks") && value >= 64 && value <= 65536) {
-        g_opt_ln_bwd_blocks = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "ln_bwd_rows") && value >= 1 && value <= 64) {
-        g_opt_ln_bwd_rows = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "gemm_big_tiles") && value >= 1 && value <= 65536) {
-        g_opt_gemm_big_tiles = value;
+    if (name && !strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) {
+        g_opt_gemm_tile = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "gemm_split") && (value == -1 || value == 0 || value == 1 || value == 2 || value == 4)) {
         g_opt_gemm_split = value;
         return TIC_OK;
     }
-    if (name && !strcmp(name, "gemm_persist") && (value == 0 || value == 1)) {
-        g_opt_gemm_persist = value;
+    if (name && !strcmp(name, "tn_streamk") && value >= 0 && value <= 4096) {   // 0 off, 1 = 256 shares, n > 1 = n shares (tests)
+        g_opt_tn_streamk = value;
         return TIC_OK;
     }
-    if (name && !strcmp(name, "gemm_pgrid") && value >= 1 && value <= 4096) {
-        g_opt_gemm_pgrid = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "gemm_stagger_mask") && value >= 0 && value < 128) {
-        g_opt_gemm_stagger_mask = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "gemm_stagger") && value >= -1 && value <= 64) {
-        g_opt_gemm_stagger = value;
-        return TIC_OK;
-    }
-#ifdef TIC_MEASURE
-    if (name && !strcmp(name, "gemm_dbg") && value >= 0 && value < 32) {   // measurement build only: garbage results by construction
-        g_opt_gemm_dbg = value;
-        return TIC_OK;
-    }
-#endif
-    if (name && !strcmp(name, "gemm_tile") && (value == 0 || value == 128 || value == 256)) {
-        g_opt_gemm_tile = value;
-        return TIC_OK;
-    }
-    if (name && !strcmp(name, "tn_block") && value >= -1 && value <= 64) {
-        g_opt_tn_block = value;
+    if (name && !strcmp(name, "tn_parts") && value >= -1 && value <= 8) {
+        g_opt_tn_parts = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "tn_mfma") && (value == 0 || value == 16 || value == 32)) {
         g_opt_tn_mfma = value;
         return TIC_OK;
     }
-    if (name && !strcmp(name, "tn_phase") && (value == 0 || value == 1)) {
-        g_opt_tn_phase = value;
+    if (name && !strcmp(name, "stream_nt") && value >= 0 && value < 16) {
+        g_opt_nt = value;
         return TIC_OK;
     }
-    if (name && !strcmp(name, "tn_streamk") && value >= 0 && value <= 4096) {   // 0 off, 1 = 256 shares, n > 1 = n shares (tests)
-        g_opt_tn_streamk = value;
+#if defined(TIC_SIM) || defined(TIC_MEASURE)
+    if (name && !strcmp(name, "nt_fault") && (value == 0 || value == 1)) {
+        g_opt_nt_fault = value;
         return TIC_OK;
     }
+#endif
+#ifdef TIC_MEASURE
+#define TIC_KNOB(NAME, VAR, LO, HI)                                      \
+    if (name && !strcmp(name, NAME) && value >= (LO) && value <= (HI)) { \
+        VAR = value;                                                     \
+        return TIC_OK;                                                   \
+    }
+    TIC_KNOB("ln_blocks", g_opt_ln_blocks, 64, 65536)
+    TIC_KNOB("attn_fwd_waves", g_opt_attn_fwd_waves, 4, 8)
+    TIC_KNOB("tn_main_bias", g_opt_tn_main_bias, 0, 64)
+    TIC_KNOB("gemm_gm", g_opt_gemm_gm, 1, 256)
+    TIC_KNOB("tn_slab", g_opt_tn_slab, 0, 1)
+    TIC_KNOB("tn_split_wgs", g_opt_tn_split_wgs, 64, 8192)
+    TIC_KNOB("tn_streamk_min_steps", g_opt_tn_streamk_min_steps, 1, 1 << 20)
+    TIC_KNOB("ln_bwd_blocks", g_opt_ln_bwd_blocks, 64, 65536)
+    TIC_KNOB("ln_bwd_rows", g_opt_ln_bwd_rows, 1, 64)
+    TIC_KNOB("gemm_big_tiles", g_opt_gemm_big_tiles, 1, 65536)
+    TIC_KNOB("gemm_stagger_mask", g_opt_gemm_stagger_mask, 0, 127)
+    TIC_KNOB("gemm_stagger", g_opt_gemm_stagger, -1, 64)
+    TIC_KNOB("gemm_dbg", g_opt_gemm_dbg, 0, 31)   // garbage results by construction
+    TIC_KNOB("tn_block", g_opt_tn_block, -1, 64)
+    TIC_KNOB("tn_phase", g_opt_tn_phase, 0, 1)
+#undef TIC_KNOB
+#endif
     return tic_fail(TIC_EINVAL, "set_option: unknown option/value %s=%d", name ? name : "(null)", value);
 }
 
@@ -208,9 +177,14 @@ extern "C" const char* tic_last_error_string(void) { return g_tic_err; }
 // ONCE by the caller; per host thread (one stream at a time).  Without it launches never split.
 #define TIC_NT_SLAB_BYTES ((size_t)192 * 32 * 512 * 16)   /* 192 producer workgroups x 256 KiB */
 static thread_local char* g_nt_scratch = nullptr;
-static unsigned g_nt_epoch = 0;
+static std::atomic<unsigned> g_nt_epoch{0};   // launch counter shared by every host thread (the flag words of two scratches may alias nothing,
+                                              // but one counter keeps every epoch unique process-wide)
 extern "C" int tic_gemm_nt_scratch(void* scratch, size_t bytes) {
     TIC_REQUIRE(!scratch || (bytes >= TIC_NT_SLAB_BYTES + 4096 && TIC_ALIGNED16(scratch)), "gemm_nt_scratch: need %zu bytes, 16-byte aligned", TIC_NT_SLAB_BYTES + 4096);
+    if (scratch) {
+        if (!g_err_host && TIC_RT_ERR_WORD(&g_err_host, &g_err_dev) != 0) return tic_fail(TIC_ELAUNCH, "gemm_nt_scratch: cannot map the host error word");
+        *(volatile unsigned*)g_err_host = 0;
+    }
     g_nt_scratch = (char*)scratch;
     return TIC_OK;
 }
@@ -275,22 +249,18 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         ++g_dbg_nt_launches;
     }
 #endif
-    // few tiles, long reduction, scratch available: 2 or 4 workgroups per tile (gemm256.h SPLITK).  K tiles per part must be even
-    // (the K loop runs tile pairs) and every workgroup must be resident at once (<= 256, one per CU)
     int split = 1;
-    if (big && g_nt_scratch && g_opt_gemm_split != 0 && g_opt_gemm_split != 1 && (epilogue == TIC_EPI_BF16 || epilogue == TIC_EPI_RESID)) {
-        const int nk_ = K / 64;
-        for (int sp = 4; sp >= 2; sp >>= 1) {
-            if (g_opt_gemm_split > 0 && sp != g_opt_gemm_split) continue;
-            if (nk_ % (2 * sp) != 0 || grid * sp > 256) continue;
-            // auto: worth it when a part still runs >= 12 K tiles (the hand-off costs about as much as 8-10 of them)
-            if (g_opt_gemm_split < 0 && (nk_ / sp < 12 || grid > 128)) continue;
-            split = sp;
-            break;
-        }
+#ifdef TIC_MEASURE
+    // measurement build only -- the 256x256 kernel's split-K form (gemm256.h SPLITK): it lost to the 128x128 kernel's at every shape it
+    // is legal for and is not part of the product library.  K tiles per part must be even, every workgroup resident at once
+    if (big && g_nt_scratch && g_opt_gemm_split > 1 && (epilogue == TIC_EPI_BF16 || epilogue == TIC_EPI_RESID)) {
+        const int nk_ = K / 64, sp = g_opt_gemm_split;
+        if (nk_ % (2 * sp) == 0 && grid * sp <= 256) split = sp;
     }
-    // the same for the 128x128 kernel (two workgroups per CU = 512 slots): 2 or 4 parts while every part keeps >= 16 K tiles and the
-    // launch still fits the slots; any epilogue (the consumer runs the ordinary one on the summed accumulators)
+#endif
+    // few tiles, long reduction (ViT-L at 8-16 images per GPU, N = 1024, K >= 3072), scratch registered: split-K form of the 128x128 kernel
+    // (two workgroups per CU = 512 slots): 2 or 4 parts while every part keeps >= 16 K tiles and the launch still fits the slots; any
+    // epilogue (the consumer runs the ordinary one on the summed accumulators)
     if (!big && g_nt_scratch && g_opt_gemm_split != 0 && g_opt_gemm_split != 1 && epilogue != TIC_EPI_PATCH && N % 128 == 0) {
         const int nk_ = K / 64;
         for (int sp = 4; sp >= 2; sp >>= 1) {
@@ -302,31 +272,32 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
             break;
         }
     }
-    p.split = split;
     p.slab = (float*)g_nt_scratch;
     p.flags = (unsigned*)(g_nt_scratch ? g_nt_scratch + TIC_NT_SLAB_BYTES : nullptr);
+    // a captured launch would replay with the epoch baked into its arguments: from the second replay the flags already hold it and the
+    // consumer would read its slabs before they are written.  Under stream capture launches never split.
+    if (split > 1 && TIC_RT_IS_CAPTURING(stream)) split = 1;
+    p.split = split;
     p.epoch = split > 1 ? ++g_nt_epoch : 0;
     if (split > 1 && p.epoch == 0) p.epoch = ++g_nt_epoch;   // 0 is what freshly zeroed flags hold
-#define TIC_GEMM_NT_LAUNCH_S(E)                                                                      \
+    p.err = g_err_dev;
+    p.fault = 0;
+#if defined(TIC_SIM) || defined(TIC_MEASURE)
+    p.fault = g_opt_nt_fault;
+#endif
+#ifdef TIC_MEASURE
+#define TIC_GEMM_NT_LAUNCH_B(E)                                                                      \
     do {                                                                                             \
         if (split > 1 && big) {                                                                      \
             TIC_RT_MAX_LDS((gemm_nt256_kernel<E, 0, 1>), G256_NT_LDS_BYTES);                         \
             TIC_LAUNCH((gemm_nt256_kernel<E, 0, 1>), grid * split, 512, G256_NT_LDS_BYTES, stream, p); \
         } else {                                                                                     \
-            TIC_GEMM_NT_LAUNCH_P(E);                                                                 \
-        }                                                                                            \
-    } while (0)
-    // more tiles than CUs and an epilogue without second-pass loads: one persistent workgroup per CU walks the tiles
-    const bool persist = big && g_opt_gemm_persist && grid > g_opt_gemm_pgrid && ((double)M + 256.0) * N * 2.0 < 4294967296.0;
-#define TIC_GEMM_NT_LAUNCH_P(E)                                                                      \
-    do {                                                                                             \
-        if (persist) {                                                                               \
-            TIC_RT_MAX_LDS(gemm_nt256p_kernel<E>, G256P_LDS_BYTES);                                  \
-            TIC_LAUNCH(gemm_nt256p_kernel<E>, g_opt_gemm_pgrid, 512, G256P_LDS_BYTES, stream, p);    \
-        } else {                                                                                     \
             TIC_GEMM_NT_LAUNCH(E);                                                                   \
         }                                                                                            \
     } while (0)
+#else
+#define TIC_GEMM_NT_LAUNCH_B(E) TIC_GEMM_NT_LAUNCH(E)
+#endif
 #define TIC_GEMM_NT_LAUNCH(E)                                                                        \
     do {                                                                                             \
         if (big) {                                                                                   \
@@ -358,24 +329,19 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
                 break;
             }
 #endif
-            TIC_GEMM_NT_LAUNCH_S(TIC_EPI_BF16);
+            TIC_GEMM_NT_LAUNCH_B(TIC_EPI_BF16);
             break;
         case TIC_EPI_GELU:
             TIC_REQUIRE(out_bf16 && out2_bf16, "gemm_nt: EPI_GELU needs out_bf16 and out2_bf16");
-            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_GELU);
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_GELU);
             break;
         case TIC_EPI_RESID:
             TIC_REQUIRE(out_f32 && resid, "gemm_nt: EPI_RESID needs out_f32 and resid");
-            if (split > 1 && big) {
-                TIC_RT_MAX_LDS((gemm_nt256_kernel<TIC_EPI_RESID, 0, 1>), G256_NT_LDS_BYTES);
-                TIC_LAUNCH((gemm_nt256_kernel<TIC_EPI_RESID, 0, 1>), grid * split, 512, G256_NT_LDS_BYTES, stream, p);
-                break;
-            }
-            TIC_GEMM_NT_LAUNCH(TIC_EPI_RESID);
+            TIC_GEMM_NT_LAUNCH_B(TIC_EPI_RESID);
             break;
         case TIC_EPI_DGELU:
             TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_DGELU needs out_bf16 and aux_bf16");
-            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_DGELU);
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_DGELU);
             break;
         case TIC_EPI_GELU_ONLY:
             TIC_REQUIRE(out2_bf16, "gemm_nt: EPI_GELU_ONLY needs out2_bf16");
@@ -383,11 +349,11 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
             break;
         case TIC_EPI_GELU_DG:
             TIC_REQUIRE(out_bf16 && out2_bf16, "gemm_nt: EPI_GELU_DG needs out_bf16 and out2_bf16");
-            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_GELU_DG);
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_GELU_DG);
             break;
         case TIC_EPI_MULAUX:
             TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_MULAUX needs out_bf16 and aux_bf16");
-            TIC_GEMM_NT_LAUNCH_P(TIC_EPI_MULAUX);
+            TIC_GEMM_NT_LAUNCH(TIC_EPI_MULAUX);
             break;
         case TIC_EPI_ADDAUX:
             TIC_REQUIRE(out_bf16 && aux_bf16, "gemm_nt: EPI_ADDAUX needs out_bf16 and aux_bf16");
@@ -401,8 +367,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
             return tic_fail(TIC_EINVAL, "gemm_nt: unknown epilogue %d", epilogue);
     }
 #undef TIC_GEMM_NT_LAUNCH
-#undef TIC_GEMM_NT_LAUNCH_P
-#undef TIC_GEMM_NT_LAUNCH_S
+#undef TIC_GEMM_NT_LAUNCH_B
     return tic_after_launch("gemm_nt");
 }
 
@@ -933,75 +898,80 @@ extern "C" int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, 
     TIC_LAUNCH(col2im_kernel, ew_grid((long)B * H * W * (Ci / 8)), 256, 0, stream, (const bf16_t*)dcol, (bf16_t*)dx, g, accumulate);
     return tic_after_launch("col2im");
 }
-// row splits of the column-reduction kernels (grid.y).  Every block ends with 2 C atomics onto the same 2 C addresses, and adds to ONE
-// address serialise at ~11 ns each: grid.y = 2048 cost 20 us per launch in atomics alone, so at most 512 (the kernels keep 4 / 2 rows
-// per thread in flight instead); and no more than leave every thread 4 rows.  A block covers R = 256 / min(C/8, 32) rows per trip.
+// row splits of the column-reduction kernels (grid.y): at most 512 (the kernels keep 4 / 2 rows per thread in flight), and no more than
+// leave every thread 4 rows.  A block covers R = 256 / min(C/8, 32) rows per trip.  Every split stores 2 C partial sums (no atomics:
+// conv.h explains why the sums must be order-independent), so the scratch is (1 + splits) x 2 C floats: [0, 2C) the final sums of the
+// backward, then one 2 C row per split.
 static int bn_rows(long M, int C) {
     const int cpb = (C / 8) < 32 ? (C / 8) : 32, R = 256 / cpb;
     long want = 512, most = (M + 4L * R - 1) / (4L * R);
     if (want > most) want = most;
     return (int)(want < 1 ? 1 : want);
 }
+extern "C" size_t tic_batchnorm_scratch_bytes(long M, int C) {
+    if (M < 1 || C < 8) return 0;
+    return (size_t)(1 + bn_rows(M, C)) * 2 * (size_t)C * sizeof(float);
+}
+#define TIC_BN_SCRATCH(name) \
+    TIC_REQUIRE(scratch && scratch_bytes >= tic_batchnorm_scratch_bytes(M, C), name ": scratch smaller than tic_batchnorm_scratch_bytes(M, C)")
 extern "C" int tic_batchnorm_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                 int64_t* num_batches, float* mean, float* rstd, float* scratch2c, const void* identity, void* y, long M, int C,
-                                 float eps, float momentum, int train, int relu, tic_stream_t stream) {
-    TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && scratch2c && y, "batchnorm_fwd: null pointer");
+                                 int64_t* num_batches, float* mean, float* rstd, void* scratch, size_t scratch_bytes, const void* identity, void* y,
+                                 long M, int C, float eps, float momentum, int train, int relu, tic_stream_t stream) {
+    TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && y, "batchnorm_fwd: null pointer");
     TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_fwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
-    if (train) {   // scratch2c: zero on entry (caller, once), left zero by bn_finalize_kernel
-        TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, bn_rows(M, C)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, scratch2c, M, C);
-    }
-    TIC_LAUNCH(bn_finalize_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, mean, rstd, running_mean, running_var, (long long*)num_batches, M, C, eps,
+    TIC_BN_SCRATCH("batchnorm_fwd");
+    float* part = (float*)scratch + 2 * C;
+    const int ns = bn_rows(M, C);
+    if (train) TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, ns), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, part, M, C);
+    TIC_LAUNCH(bn_finalize_kernel, (C + BN_SUM_CH - 1) / BN_SUM_CH, 256, 2 * 256 * 4, stream, part, ns, mean, rstd, running_mean, running_var, (long long*)num_batches, M, C, eps,
                momentum, train);
     TIC_LAUNCH(bn_apply_kernel, ew_grid(M * (C / 8)), 256, 0, stream, (const bf16_t*)x, mean, rstd, gamma, beta, (const bf16_t*)identity, (bf16_t*)y, M, C, relu);
     return tic_after_launch("batchnorm_fwd");
 }
-__global__ void __launch_bounds__(256) bn_param_grad_kernel(float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
-    const int c = TIC_BID_X * 256 + TIC_TID;
-    if (c < C) {
-        dbeta[c] += red[c];
-        dgamma[c] += red[C + c];
-        red[c] = 0.f;       // consumed: left zero for the next launch that accumulates into it
-        red[C + c] = 0.f;
-    }
-}
 static int batchnorm_bwd_impl(const void* dy, const void* y_or_null, const void* x, const float* mean, const float* rstd, const float* gamma,
-                              const float* beta_mask, float* scratch2c, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M,
-                              int C, tic_stream_t stream) {
-    TIC_REQUIRE(dy && x && mean && rstd && gamma && scratch2c && dx && dgamma && dbeta, "batchnorm_bwd: null pointer");
+                              const float* beta_mask, void* scratch, size_t scratch_bytes, void* dx, void* dskip, int skip_accumulate, float* dgamma,
+                              float* dbeta, long M, int C, tic_stream_t stream) {
+    TIC_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "batchnorm_bwd: null pointer");
     TIC_REQUIRE(M >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "batchnorm_bwd: need C/8 to divide 256 (C = 64 .. 2048, powers of two)");
     TIC_REQUIRE(!(y_or_null && beta_mask), "batchnorm_bwd: the ReLU mask comes from y OR from x, not both");
-    // scratch2c: zero on entry (caller, once), left zero by bn_param_grad_kernel
-    TIC_LAUNCH(bn_bwd_reduce_kernel, dim3((C + 255) / 256, bn_rows(M, C)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null,
-               (const bf16_t*)x, mean, rstd, scratch2c, M, C, gamma, beta_mask ? beta_mask : gamma, beta_mask ? 1 : 0);
+    TIC_BN_SCRATCH("batchnorm_bwd");
+    float* red = (float*)scratch;
+    float* part = red + 2 * C;
+    const int ns = bn_rows(M, C);
+    TIC_LAUNCH(bn_bwd_reduce_kernel, dim3((C + 255) / 256, ns), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null,
+               (const bf16_t*)x, mean, rstd, part, M, C, gamma, beta_mask ? beta_mask : gamma, beta_mask ? 1 : 0);
+    TIC_LAUNCH(bn_param_grad_kernel, (C + BN_SUM_CH - 1) / BN_SUM_CH, 256, 2 * 256 * 4, stream, part, ns, red, dgamma, dbeta, C);
     TIC_LAUNCH(bn_bwd_apply_kernel, ew_grid(M * (C / 8)), 256, 0, stream, (const bf16_t*)dy, (const bf16_t*)y_or_null, (const bf16_t*)x, mean, rstd, gamma,
-               scratch2c, (bf16_t*)dx, (bf16_t*)dskip, skip_accumulate, M, C, beta_mask ? beta_mask : gamma, beta_mask ? 1 : 0);
-    TIC_LAUNCH(bn_param_grad_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, dgamma, dbeta, C);
+               red, (bf16_t*)dx, (bf16_t*)dskip, skip_accumulate, M, C, beta_mask ? beta_mask : gamma, beta_mask ? 1 : 0);
     return tic_after_launch("batchnorm_bwd");
 }
 extern "C" int tic_batchnorm_bwd(const void* dy, const void* y_or_null, const void* x, const float* mean, const float* rstd, const float* gamma,
-                                 float* scratch2c, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M, int C,
-                                 tic_stream_t stream) {
-    return batchnorm_bwd_impl(dy, y_or_null, x, mean, rstd, gamma, nullptr, scratch2c, dx, dskip, skip_accumulate, dgamma, dbeta, M, C, stream);
+                                 void* scratch, size_t scratch_bytes, void* dx, void* dskip, int skip_accumulate, float* dgamma, float* dbeta, long M,
+                                 int C, tic_stream_t stream) {
+    return batchnorm_bwd_impl(dy, y_or_null, x, mean, rstd, gamma, nullptr, scratch, scratch_bytes, dx, dskip, skip_accumulate, dgamma, dbeta, M, C, stream);
 }
 // backward of y = relu(bn(x)) WITHOUT a residual add: the ReLU mask is recomputed from x (bit-identical to the forward's), y is not read
 extern "C" int tic_batchnorm_bwd_relu(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                      float* scratch2c, void* dx, float* dgamma, float* dbeta, long M, int C, tic_stream_t stream) {
+                                      void* scratch, size_t scratch_bytes, void* dx, float* dgamma, float* dbeta, long M, int C, tic_stream_t stream) {
     TIC_REQUIRE(beta, "batchnorm_bwd_relu: null beta");
-    return batchnorm_bwd_impl(dy, nullptr, x, mean, rstd, gamma, beta, scratch2c, dx, nullptr, 0, dgamma, dbeta, M, C, stream);
+    return batchnorm_bwd_impl(dy, nullptr, x, mean, rstd, gamma, beta, scratch, scratch_bytes, dx, nullptr, 0, dgamma, dbeta, M, C, stream);
 }
 // The ResNet stem's tail in one piece (TIC/ResNet/model.py:150-152: bn1 -> relu -> maxpool): y_pool = maxpool3x3/2(relu(bn(x))) and the
 // argmax positions, WITHOUT storing relu(bn(x)).  Bit-identical to tic_batchnorm_fwd(relu) + tic_maxpool3x3s2_fwd_idx; the backward is
 // tic_maxpool3x3s2_bwd_idx + tic_batchnorm_bwd_relu (fusing those too was measured slower: both BatchNorm passes would repeat the
-// window gather, 462 + 343 us against 207 + 160 + 240).  scratch2c as in tic_batchnorm_fwd (zero on entry, left zero).
+// window gather, 462 + 343 us against 207 + 160 + 240).  scratch as in tic_batchnorm_fwd with M = B H W.
 extern "C" int tic_bn_relu_maxpool_fwd(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var, int64_t* num_batches,
-                                       float* mean, float* rstd, float* scratch2c, void* y_pool, void* idx_u8_or_null, int B, int H, int W, int C, float eps,
-                                       float momentum, int train, tic_stream_t stream) {
-    TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && scratch2c && y_pool, "bn_relu_maxpool_fwd: null pointer");
+                                       float* mean, float* rstd, void* scratch, size_t scratch_bytes, void* y_pool, void* idx_u8_or_null, int B, int H, int W,
+                                       int C, float eps, float momentum, int train, tic_stream_t stream) {
+    TIC_REQUIRE(x && gamma && beta && running_mean && running_var && mean && rstd && y_pool, "bn_relu_maxpool_fwd: null pointer");
     TIC_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 8 && C % 8 == 0 && 256 % (C / 8) == 0, "bn_relu_maxpool_fwd: need C/8 to divide 256");
     const long M = (long)B * H * W;
+    TIC_BN_SCRATCH("bn_relu_maxpool_fwd");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    if (train) TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, bn_rows(M, C)), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, scratch2c, M, C);
-    TIC_LAUNCH(bn_finalize_kernel, (C + 255) / 256, 256, 0, stream, scratch2c, mean, rstd, running_mean, running_var, (long long*)num_batches, M, C, eps,
+    float* part = (float*)scratch + 2 * C;
+    const int ns = bn_rows(M, C);
+    if (train) TIC_LAUNCH(bn_stats_kernel, dim3((C + 255) / 256, ns), 256, 2 * 8 * 256 * 4, stream, (const bf16_t*)x, part, M, C);
+    TIC_LAUNCH(bn_finalize_kernel, (C + BN_SUM_CH - 1) / BN_SUM_CH, 256, 2 * 256 * 4, stream, part, ns, mean, rstd, running_mean, running_var, (long long*)num_batches, M, C, eps,
                momentum, train);
     TIC_LAUNCH(bn_relu_maxpool_fwd_kernel, ew_grid((long)B * Ho * Wo * (C / 8)), 256, 0, stream, (const bf16_t*)x, mean, rstd, gamma, beta, (bf16_t*)y_pool,
                (unsigned char*)idx_u8_or_null, B, H, W, C, Ho, Wo);

@@ -2,6 +2,7 @@
 // Build:  hipcc --offload-arch=gfx950 -O3 -fPIC -shared tic_hip.hip -o libtic_hip.so   (see build.py)
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <atomic>
 
 static inline const char* tic_rt_last_error() {
     const hipError_t e = hipGetLastError();
@@ -29,6 +30,24 @@ static inline const char* tic_rt_last_error() {
             done_ = true;                                                                                         \
         }                                                                                                         \
     } while (0)
+
+static inline int tic_rt_err_word(unsigned** host, unsigned** dev) {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return -1;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) return -1;
+    *host = (unsigned*)h;
+    *dev = (unsigned*)d;
+    **host = 0;
+    return 0;
+}
+#define TIC_RT_ERR_WORD(host, dev) tic_rt_err_word((host), (dev))
+static inline int tic_rt_is_capturing(void* stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) return 0;
+    return st != hipStreamCaptureStatusNone;
+}
+#define TIC_RT_IS_CAPTURING(stream) tic_rt_is_capturing(stream)
 
 // ---- live kernel timer (bench.py roofline): HIP events around every grouped-dW launch, on the launch stream ----------
 #define TIC_TIMER_SLOTS 8192

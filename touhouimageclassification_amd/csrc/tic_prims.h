@@ -172,15 +172,19 @@ TIC_DEV void flag_publish(unsigned* flag, unsigned value) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // always: hipcc can drop the fence's own wait (guide, compiler hazard)
     __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-TIC_DEV bool flag_wait(const unsigned* flag, unsigned value) {
+// A poll that runs out (a producer that was never dispatched or died) must not pass silently: the consumer would add an unwritten or
+// stale slab and store a normal-looking tile.  It reports through `err`, one word of HOST memory mapped into the device (system-scope
+// store), which the library checks at the start and end of every later call (tic_after_launch: TIC_ELAUNCH, sticky).
+TIC_DEV bool flag_wait(const unsigned* flag, unsigned value, unsigned* err) {
     bool ok = false;
-    for (int spin = 0; spin < (1 << 22); ++spin) {   // ~ seconds at most, then give up (garbage output, terminated kernel)
+    for (int spin = 0; spin < (1 << 22); ++spin) {   // ~ seconds at most, then give up and REPORT
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == value) {
             ok = true;
             break;
         }
         __builtin_amdgcn_s_sleep(8);
     }
+    if (!ok && err) __hip_atomic_store(err, 0xDEAD0000u | (value & 0xFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return ok;

@@ -2,8 +2,8 @@
 
 The reference has no distributed code; this is the one exchange the data-parallel step needs.
 Images shard across ranks with no data-path collective; each rank's backward fires a hook per gradient
-bucket (head, layer L-1 .. 0, embed -- each a CONTIGUOUS range of the flat fp32 gradient buffer, 50 MB per
-ViT-L layer), and the bucket is all-reduced on a side HIP stream while earlier layers' backward still
+bucket (ViT: head, layer L-1 .. 0, embed, 50 MB per ViT-L layer; ResNet: fc, layer4 .. layer1, stem -- each a
+CONTIGUOUS range of the model's flat fp32 gradient buffer, `model.buckets()`), and the bucket is all-reduced on a side HIP stream while earlier layers' backward still
 runs.  Averaging is folded into the loss gradient (dlogits scaled by 1/world), so the collective is a
 plain SUM and no extra pass over the gradients is needed.  The optimizer waits on the side stream.
 """
@@ -45,7 +45,7 @@ class BucketedGradSync:
             dist.all_reduce(grad_slice, op=dist.ReduceOp.SUM, group=self.pg)
             return
         if self._wire is None or self._wire.numel() < grad_slice.numel() or self._wire.device != grad_slice.device:
-            self._wire = torch.empty(max(b - a for _, a, b in self.model._engine.buckets()), dtype=torch.bfloat16, device=grad_slice.device)
+            self._wire = torch.empty(max(b - a for _, a, b in self.model.buckets()), dtype=torch.bfloat16, device=grad_slice.device)
         wire = self._wire[:grad_slice.numel()]
         wire.copy_(grad_slice)
         dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.pg)
@@ -77,5 +77,19 @@ class BucketedGradSync:
     def broadcast_parameters(self, src: int = 0) -> None:
         """one-time parameter broadcast at start-up (replicas must start identical)"""
         if self.active:
-            dist.broadcast(self.model._engine.params, src=src, group=self.pg)
-            self.model._engine.mark_weights_dirty()
+            self.model.broadcast_state(src, self.pg)   # ViT: the flat master weights; ResNet: parameters + BatchNorm buffers
+
+
+class UnpaddedShardSampler(torch.utils.data.Sampler):
+    """rank r of w evaluates samples r, r + w, r + 2w, ...: every sample exactly once over the ranks.  `DistributedSampler` pads the
+    shards to equal length by REPEATING samples, which counts up to w - 1 samples twice in a validation / test metric; evaluation has
+    no per-batch collective, so the shards need not be equally long (the sums are all-reduced once at the end)."""
+
+    def __init__(self, dataset, num_replicas: int, rank: int):
+        self.n, self.world, self.rank = len(dataset), num_replicas, rank
+
+    def __iter__(self):
+        return iter(range(self.rank, self.n, self.world))
+
+    def __len__(self):
+        return len(range(self.rank, self.n, self.world))
