@@ -14,6 +14,9 @@ Rank 0 prints ONE JSON line.
   cpu_baseline  the CPU oracle (oracle/vit_oracle.py, a port) timed on this box's host cores, N = 1 only:
                 3 warm-up + 5 timed steps, median; headline config in fp32, `also` = bf16-autocast and BASELINE config 1
   sweep         per-GPU batch {8, 16, 32, 64, 128} (8 / 16: what the reference's ntrain*.py launchers set; 32-128: SURVEY 8d), outside the headline timed region
+  secondary     N = 1: BASELINE config 2 (ViT-B C=10 batch 256), config 4 (ResNet-50 @224 batch 256), the reference's own ResNet run
+                (ResNet-152 @256 batch 80, TIC/ResNet/train.py:213) and forward-only ViT-L at batch 1 / 64 / 256 -- each with img/s, ms/step
+                and the fraction of the bound it is measured against (ResNet: max of the MFMA time and BatchNorm's 22 B/element at 8 TB/s)
   dp            N > 1: RCCL rank count actually observed, per-rank ms/step min / max, all-reduce time not hidden by backward
 """
 import argparse
@@ -144,6 +147,107 @@ def parity_block(hip_logits, hip_loss, ref_logits, ref_loss, y):
                 tolerance="logits atol 2e-2 + rtol 2e-2, loss rtol 1e-2 (tests/test_gpu_model.py)")
 
 
+# ---- secondary configurations (N = 1, outside the headline timed region) ------------------------------------------------------------
+def _timeit(step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def resnet_work_per_image(model, image):
+    """-> (train FLOPs, BatchNorm HBM bytes) per image.  FLOPs = 3 x forward conv + fc (8.174 GFLOP forward for ResNet-50
+    @224).  Bytes = 22 B per BatchNorm-ed activation element over its five passes (statistics 2, apply 2 + 2, backward reduce 4 + 2 .. 6,
+    backward apply 6 + 2 .. 8; DESIGN.md 4: the measured average), the term that bounds the ResNet step"""
+    def conv(c, h):
+        ho = (h + 2 * c.pad - c.k) // c.stride + 1
+        return 2.0 * ho * ho * c.cout * c.cin * c.k * c.k, ho, ho * ho * c.cout
+    fl, h, el = conv(model.conv1, image)
+    h = (h + 2 - 3) // 2 + 1
+    for blk in model._blocks():
+        f, hm, e = conv(blk.conv1, h)
+        fl, el = fl + f, el + e
+        f, ho, e = conv(blk.conv2, hm)
+        fl, el = fl + f, el + e
+        if blk.kind != "basic":
+            f, ho, e = conv(blk.conv3, ho)
+            fl, el = fl + f, el + e
+        if blk.downsample is not None:
+            f, _, e = conv(blk.downsample[0], h)
+            fl, el = fl + f, el + e
+        h = ho
+    fl += 2.0 * model.fc.weight.shape[1] * model.fc.weight.shape[0]
+    return 3.0 * fl, 22.0 * el
+
+
+def secondary_legs(dev, vit_l, x_l, steps=8, warmup=3):
+    """BASELINE configs 2 and 4, the configuration the reference's ResNet harness trains (TIC/ResNet/train.py:210-255: ResNet-152 @256 px,
+    batch 80) and the forward-only path (validate_step / serve), each timed on this GPU in this run.  vit_l: the headline model (its
+    forward-only numbers come first; it is released before the other models are built)."""
+    from touhouimageclassification_amd.ViT.model import ViT
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from touhouimageclassification_amd.step import fused_train_step
+    from touhouimageclassification_amd.ResNet import model as rm
+    out = []
+    fwd_fl = train_flops_per_image(MODELS["large"], vit_l.num_labels) / 3.0
+    vit_l.eval()
+    for b in (1, 64, 256):
+        xb = x_l[:b].contiguous()
+        with torch.no_grad():
+            dt = _timeit(lambda: vit_l(xb), 20 if b < 256 else steps, warmup)
+        out.append(dict(config=f"ViT-L/16 C={vit_l.num_labels} forward only (validate_step / serve), batch {b}", value=round(b / dt, 1), unit="images/sec",
+                        ms_per_step=round(1e3 * dt, 3), bound="mfma", frac=round(b / dt * fwd_fl / 1e12 / PEAK_BF16_TFLOPS, 4)))
+    return out
+
+
+def secondary_train_legs(dev, steps=8, warmup=3):
+    from touhouimageclassification_amd.ViT.model import ViT
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from touhouimageclassification_amd.step import fused_train_step
+    from touhouimageclassification_amd.ResNet import model as rm
+    out = []
+    g = torch.Generator().manual_seed(77)
+    # BASELINE config 2: ViT-Base/16, global batch 256 on one GPU
+    mb = MODELS["base"]
+    torch.manual_seed(0)
+    vb = ViT(10, pretrained=False, model_name=mb["name"]).to(dev)
+    ob = FusedAdamW(vb, lr=1e-5, weight_decay=0.01)
+    xb = torch.randn(256, 3, 224, 224, generator=g).to(dev)
+    yb = torch.randint(0, 10, (256,), generator=g).to(dev)
+    dt = _timeit(lambda: fused_train_step(vb, ob, xb, yb, None), steps, warmup)
+    out.append(dict(config="BASELINE config 2: ViT-B/16 C=10 fine-tune step, batch 256, 1 GPU", value=round(256 / dt, 1), unit="images/sec",
+                    ms_per_step=round(1e3 * dt, 3), bound="mfma", frac=round(256 / dt * train_flops_per_image(mb, 10) / 1e12 / PEAK_BF16_TFLOPS, 4)))
+    del vb, ob, xb, yb
+    torch.cuda.empty_cache()
+    # BASELINE config 4 (ResNet-50 @224, batch 256) and the reference's own ResNet configuration (ResNet-152 @256, batch 80), SGD lr 5e-2
+    for arch, image, batch, what in (("resnet50", 224, 256, "BASELINE config 4: ResNet-50 224px"), ("resnet152", 256, 80, "TIC/ResNet/train.py:210-255: ResNet-152 256px")):
+        torch.manual_seed(0)
+        m = getattr(rm, arch)(num_classes=120).to(dev).train()
+        opt = torch.optim.SGD(m.parameters(), lr=5e-2)
+        xr = torch.randn(batch, 3, image, image, generator=g).to(dev)
+        yr = torch.randint(0, 120, (batch,), generator=g).to(dev)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(m(xr), yr).backward()
+            opt.step()
+        dt = _timeit(step, steps, warmup)
+        fl, by = resnet_work_per_image(m, image)
+        t_mfma, t_hbm = batch * fl / (PEAK_BF16_TFLOPS * 1e12), batch * by / 8e12
+        out.append(dict(config=f"{what} C=120 train step (fwd+CE+bwd+SGD), batch {batch}, 1 GPU", value=round(batch / dt, 1), unit="images/sec",
+                        ms_per_step=round(1e3 * dt, 3), bound="hbm" if t_hbm > t_mfma else "mfma",
+                        frac=round(max(t_mfma, t_hbm) / dt, 4), mfma_frac=round(t_mfma / dt, 4),
+                        bound_ms=dict(mfma=round(1e3 * t_mfma, 3), hbm_batchnorm_22B_per_element=round(1e3 * t_hbm, 3)),
+                        flops_per_image=fl, batchnorm_bytes_per_image=by))
+        del m, opt, xr, yr
+        torch.cuda.empty_cache()
+    return out
+
+
 # ---- launching N ranks ourselves ------------------------------------------------------------------------------------------------
 def _free_port():
     with socket.socket() as s:
@@ -176,6 +280,7 @@ def main():
     ap.add_argument("--classes", type=int, default=120)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (ViT-B B=256, ResNet-50 / -152, forward-only ViT-L)")
     ap.add_argument("--sweep", default="8,16,32,64,128", help="per-GPU batch sizes reported beside the headline")
     ap.add_argument("--autograd", action="store_true", help="drive the step through torch autograd + F.cross_entropy (plugin surface) instead of the fused step")
     ap.add_argument("--aug", action="store_true", help="BASELINE config 3: include the on-GPU augmentation (uint8 256x256 thumbnails -> crop/flip/jitter/gray/erase/normalise) and MixUp/CutMix (soft labels) in every timed step")
@@ -376,6 +481,14 @@ def main():
             out["dp"] = dp
         if sweep:
             out["sweep"] = sweep
+        if world == 1 and not args.no_secondary and not args.aug and not args.autograd:
+            print("[bench] secondary configurations ...", file=sys.stderr, flush=True)
+            sec = secondary_legs(dev, model, x) if args.model == "large" else []
+            model.train()
+            model.to("cpu")          # release the headline replica's HBM (weights, gradients, workspaces) before the other models are built
+            del opt
+            torch.cuda.empty_cache()
+            out["secondary"] = sec + secondary_train_legs(dev)
         if not args.no_cpu_baseline:
             if world == 1:
                 base, first = cpu_legs(args.model, C, init_params, x_cpu[:4], y_cpu[:4])

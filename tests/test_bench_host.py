@@ -27,3 +27,12 @@ def test_self_launch_starts_ranks_and_forwards_failure():
     assert r.returncode != 0
     assert "starting 2 ranks" in r.stderr
     assert "bench.py needs an MI355X" in r.stderr and "AssertionError" not in r.stderr
+
+
+def test_resnet_work_per_image_matches_the_survey():
+    """ResNet-50 @224 = 8.174 GFLOP forward conv (+ fc); 53 BatchNorm-ed tensors = 11.1 M elements per image"""
+    import bench
+    from touhouimageclassification_amd.ResNet.model import resnet50
+    fl, by = bench.resnet_work_per_image(resnet50(num_classes=120), 224)
+    assert abs(fl / 3.0 - (8.174e9 + 2 * 2048 * 120)) < 2e7
+    assert 10.5e6 < by / 22.0 < 11.5e6

@@ -73,7 +73,7 @@ def main(data_dir: str = UNFILTERED_DATA_DIR, batch_size: int = 80, num_epochs: 
     num_classes = len(dataset.classes)
     logger.info(f"Dataset loaded. Number of classes: {num_classes}")
     model, optimizer, scheduler, criterion = build_reference_setup(num_classes, lr, arch)
-    model.to(device or "cuda")
+    model.to(device or _loop.init_distributed_from_env() or "cuda")
     logger.info("Starting model training...")
     timeline = train_model(model, dataset, optimizer, scheduler, criterion, num_epochs=num_epochs, batch_size=batch_size,
                            max_tolerant_epoch=max_tolerant_epoch, save_path=save_path, logger=logger, skip_optimizer_load=True,

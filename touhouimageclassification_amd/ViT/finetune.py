@@ -51,6 +51,23 @@ def get_linear_schedule_with_warmup(optimizer, num_warmup_steps: int, num_traini
     return torch.optim.lr_scheduler.LambdaLR(optimizer, factor, last_epoch)
 
 
+def init_distributed_from_env() -> Optional[str]:
+    """`torchrun --nproc-per-node N -m ...ViT.finetune` / `...ResNet.train` (one process per GPU): joins the RCCL group the launcher
+    describes (WORLD_SIZE / RANK / LOCAL_RANK / MASTER_*) and returns this rank's device; None when not launched that way.  The
+    reference is single-process (finetune.py:313 hard-codes "cuda")."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not dist.is_initialized():
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+    return f"cuda:{local}" if torch.cuda.is_available() else "cpu"
+
+
 def _device_of(model) -> torch.device:
     return next(model.parameters()).device
 
@@ -271,7 +288,7 @@ def main(data_dir: Optional[str] = None, num_epochs: int = 40, batch_size: int =
         dataset = get_dataset(data_dir=data_dir, image_size=VIT_IMAGE_SIZE)
     num_classes = len(dataset.classes)
     logger.info(f"Dataset loaded. Number of classes: {num_classes}")
-    model = ViT(num_classes=num_classes, pretrained=use_pretrained, model_name=model_name).to(device or "cuda")
+    model = ViT(num_classes=num_classes, pretrained=use_pretrained, model_name=model_name).to(device or init_distributed_from_env() or "cuda")
     optimizer = FusedAdamW(model, lr=lr, weight_decay=weight_decay)   # AdamW(model.parameters(), ...) semantics, one HIP kernel
     criterion = torch.nn.CrossEntropyLoss()
     num_training_steps = (len(dataset) - len(dataset) // 10) // batch_size * num_epochs

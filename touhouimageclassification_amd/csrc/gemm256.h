@@ -263,8 +263,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(GemmNtParams p) {
 #ifndef TIC_SIM
     // experiment: delay every other workgroup of the first wave of tiles so that epilogues (HBM bursts) of one half of the
     // CUs fall into the main loops of the other half
-    if (p.stagger > 0 && TIC_BID_X < 256 && ((TIC_BID_X >> 3) & 1))   // the host zeroes it for epilogues outside "gemm_stagger_mask"
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    // (bits 8..15 of p.stagger: number of groups G, default 2: group g = (index within the XCD) % G sleeps g x rounds)
+    if ((p.stagger & 255) > 0 && TIC_BID_X < 256) {   // the host zeroes it for epilogues outside "gemm_stagger_mask"
+        const int G = (p.stagger >> 8) > 1 ? (p.stagger >> 8) : 2;
+        const int rounds = (p.stagger & 255) * ((TIC_BID_X >> 3) % G);
+        for (int i = 0; i < rounds; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 #endif
     const tic_rsrc_t ra = make_rsrc(p.A, (uint32_t)((size_t)p.M * p.K * 2));
     const tic_rsrc_t rb = make_rsrc(p.B, (uint32_t)((size_t)p.N * p.K * 2));

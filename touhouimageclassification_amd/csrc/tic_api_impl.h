@@ -89,6 +89,7 @@ static int g_opt_ln_bwd_rows = 2;        // LayerNorm backward: fewest rows per 
 static int g_opt_gemm_big_tiles = 128;   // fewest 256x256 tiles for which the 256x256 NT kernel is chosen (gemm_tile = 0)
 static int g_opt_gemm_split = -1;       // split-K form of the 128x128 NT kernel (and, measurement build, the 256x256 one): -1 auto, 0 / 1 never, 2 / 4 forced where legal
 static int g_opt_gemm_stagger_mask = 0x7f;   // bit e: apply "gemm_stagger" to epilogue e
+static int g_opt_gemm_stagger_groups = 2; // groups of first-round workgroups; group g starts g x gemm_stagger sleep rounds late
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
 static int g_opt_tn_block = -1;   // tile-walk block width of the grouped dW launch: -1 auto (one XCD share per block), 0 row-major, n fixed
@@ -150,6 +151,7 @@ extern "C" int tic_set_option(const char* name, int value) {
     TIC_KNOB("gemm_big_tiles", g_opt_gemm_big_tiles, 1, 65536)
     TIC_KNOB("gemm_stagger_mask", g_opt_gemm_stagger_mask, 0, 127)
     TIC_KNOB("gemm_stagger", g_opt_gemm_stagger, -1, 64)
+    TIC_KNOB("gemm_stagger_groups", g_opt_gemm_stagger_groups, 2, 32)
     TIC_KNOB("gemm_dbg", g_opt_gemm_dbg, 0, 31)   // garbage results by construction
     TIC_KNOB("tn_block", g_opt_tn_block, -1, 64)
     TIC_KNOB("tn_phase", g_opt_tn_phase, 0, 1)
@@ -235,7 +237,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     // chip alternate between epilogue and main loop.  Stand-alone back-to-back launches of fc1+GELU gain 11 %
     // (tools/stagger_probe.py); inside the training step the gain is zero (tools/ab_step.py gemm_stagger 0 2: 141.8 vs
     // 141.9 ms) -- there the previous kernel's tail already starts the CUs at different times.
-    p.stagger = (g_opt_gemm_stagger > 0 && ((g_opt_gemm_stagger_mask >> epilogue) & 1)) ? g_opt_gemm_stagger : 0;
+    p.stagger = (g_opt_gemm_stagger > 0 && ((g_opt_gemm_stagger_mask >> epilogue) & 1)) ? (g_opt_gemm_stagger | (g_opt_gemm_stagger_groups << 8)) : 0;
     p.nt = (g_opt_nt >> 2) & 3;
     p.gm = g_opt_gemm_gm;
 #ifdef TIC_MEASURE
