@@ -182,6 +182,8 @@ int tic_mix_labels(const int64_t* y, float* out, int B, int ncls, float lam, tic
  * Kp = kh*kw*Ci rounded up to 64 (tap-major k = (ky*kw+kx)*Ci + c); 1x1 stride-1 convs use X itself as col(X). */
 /* transposed = 1 writes [Kp, Co] (the B operand of the explicit dgrad GEMM); transposed = 2 writes the implicit-GEMM dgrad
  * filter [Ci][(ky',kx')*Co + o] = w[o][c][kh-1-ky'][kw-1-kx']                                   model.py:8-9,14,148 */
+/* transposed = 3: the STEM layout [Co, 256] of the implicit 7x7 / 2 stem (Ci = 3, kh = kw = 7): k = ky*32 + px*4 + c over 7 filter rows x
+ * 8 pixels x 4 channels, px = kx + 1 (px 0, c = 3 and row 7 are zeros) -- the filter as it meets an image whose 3 channels are padded to 4 */
 int tic_conv_weight_pack(const float* w_oihw, void* w16_ohwi, int Co, int Ci, int kh, int kw, int transposed, tic_stream_t stream);
 /* Implicit-GEMM convolution (no im2col buffer) for filters with Cin % 64 == 0 -- the 3x3 convolutions of TIC/ResNet/model.py:6-9
  * (Bottleneck conv2 :87, BasicBlock conv1/conv2 :31-36).  x is NHWC bf16, w_pack = tic_conv_weight_pack(..., transposed = 0).
@@ -192,7 +194,10 @@ int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, i
                        int stride, int pad, tic_stream_t stream);
 int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* dw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                          int stride, int pad, tic_stream_t stream);
-int tic_conv_weight_grad(const float* dw_ohwi, float* grad_oihw, int Co, int Ci, int kh, int kw, tic_stream_t stream); /* grad += */
+/* The 7x7 / 2, pad 3 stem (model.py:148) is an implicit GEMM too: pass the image as NHWC with 4 channels per pixel (tic_nchw_to_nhwc_pad_bf16,
+ * Cpad = 4: 8-byte pixels, so the aligned 8-pixel window of a filter row is four 16-byte chunks), Cin = 4, kh = kw = 7, stride 2, pad 3, an even
+ * W, and w_pack / dw in layout 3 ([Cout, 256]).  No im2col buffer (1.2 GB at 256 images) is written or read. */
+int tic_conv_weight_grad(const float* dw_ohwi, float* grad_oihw, int Co, int Ci, int kh, int kw, int layout, tic_stream_t stream); /* grad +=; layout 0 | 3 */
 /* optional scratch for few-tile weight gradients (tic_gemm_tn_bf16 with N, K multiples of 256, M >= 8192, <= 64 tiles: the 1 x 1
  * convolutions of a deep ResNet stage): every tile is cut into row parts that STORE their partial tiles into the scratch and one more
  * launch adds them to C, instead of stream-K shares that each add a whole tile with fp32 atomics.  Caller-owned, per host thread, 64 MiB
@@ -208,11 +213,12 @@ typedef struct {
 typedef struct {
     const float* dw; /* [Co, Kp] fp32 (tap-major) */
     float* grad;     /* OIHW fp32, += */
-    int Co, Ci, kh, kw;
+    int Co, Ci, kh, kw, layout, pad_; /* layout: 0 tap-major [Co, Kp] | 3 the stem's [Co, 256] */
 } TicConvGradDesc;
 int tic_conv_weight_pack_many(const TicConvPackDesc* descs, int n, tic_stream_t stream);
 int tic_conv_weight_grad_many(const TicConvGradDesc* descs, int n, tic_stream_t stream);
 int tic_nchw_to_nhwc_bf16(const float* x, void* out_bf16, int B, int C, int H, int W, tic_stream_t stream);
+int tic_nchw_to_nhwc_pad_bf16(const float* x, void* out_bf16, int B, int C, int Cpad, int H, int W, tic_stream_t stream); /* channels C..Cpad-1 = 0 */
 int tic_im2col_bf16(const void* x, void* col, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, tic_stream_t stream);
 int tic_col2im_bf16(const void* dcol, void* dx, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, int accumulate,
                     tic_stream_t stream);

@@ -83,7 +83,7 @@ class _Harness:
         for c in (m for top in mods for m in top.modules() if isinstance(m, self.rm._Conv)):
             packed = c.__dict__["_packed"] = {}
             for t in host._pack_variants(c):
-                shape = {0: (c.cout, c.kp), 1: (c.kp, c.cout), 2: (c.cin, c.k * c.k * c.cout)}[t]
+                shape = {0: (c.cout, c.kp), 1: (c.kp, c.cout), 2: (c.cin, c.k * c.k * c.cout), 3: (c.cout, c.kp)}[t]
                 packed[t] = torch.empty(shape, dtype=torch.bfloat16, device=dev)
                 host._call("tic_conv_weight_pack", c.weight.data_ptr(), packed[t].data_ptr(), c.cout, c.cin, c.k, c.k, t)
             c.__dict__["_dw_view"] = torch.zeros(c.cout * c.kp, device=dev)
@@ -97,7 +97,7 @@ class _Harness:
     def fold(self, mods):
         host = self.host
         for c in (m for top in mods for m in top.modules() if isinstance(m, self.rm._Conv)):
-            host._call("tic_conv_weight_grad", c.__dict__["_dw_view"].data_ptr(), c.weight.grad.data_ptr(), c.cout, c.cin, c.k, c.k)
+            host._call("tic_conv_weight_grad", c.__dict__["_dw_view"].data_ptr(), c.weight.grad.data_ptr(), c.cout, c.cin, c.k, c.k, 3 if c.stem else 0)
         host.backend.call("tic_gemm_tn_scratch", None, 0)
         if self.dev.type == "cuda":
             torch.cuda.synchronize()
@@ -119,6 +119,8 @@ def check_conv_units(backend, dev, golden_dir):
         x = g[f"{tag}/x"]
         B, _, H, W = x.shape
         xin = _nhwc(x, dev).view(B, H, W, cin)
+        if stem:   # the model hands the stem its image with the 3 channels zero-padded to 4 (8-byte pixels: TicResNet._forward_impl)
+            xin = torch.cat([xin, torch.zeros(B, H, W, 1, dtype=torch.bfloat16, device=dev)], -1).contiguous()
         y, col, Ho, Wo = hz.host._conv_fwd(conv, xin, B, H, W)
         _check(f"{tag} y", _nchw(y, B, Ho, Wo), g[f"{tag}/y"])
         dy = _nhwc(g[f"{tag}/dy"], dev)

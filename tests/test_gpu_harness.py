@@ -396,6 +396,68 @@ def test_expert_parallel_two_ranks_match_dense_on_gpu(tmp_path):
         hr.le("test_gpu_harness.py:393", (got["gate_grad"] - refg).norm(), 0.05 * refg.norm() + 1e-6)
 
 
+def _sparse_ep_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # two ranks on ONE GPU: RCCL refuses a duplicate device
+    from touhouimageclassification_amd.ResMoE.model import SparseExpertParallelMoE, make_ViTMoE
+    from touhouimageclassification_amd.ResMoE import train as mt
+    E, C, B = 2, 10, 3
+    torch.manual_seed(11)
+    dense = make_ViTMoE(num_classes=C, num_experts=E, top_k=1, gateway_t=0.01, pretrained=False, model_name="tiny", gate_pretrained=False,
+                        gate_model_name="tiny").to(DEV)
+    ep = SparseExpertParallelMoE(dense.experts[rank], dense.gate, C)
+    ep.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(E * B, 3, 224, 224, generator=g)
+    y = torch.randint(0, C, (E * B,), generator=g)
+    xs, ys = x[rank * B:(rank + 1) * B].to(DEV), y[rank * B:(rank + 1) * B].to(DEV)
+    logits, gw, idx = ep(xs)
+    loss = mt.total_loss(logits, torch.nn.functional.one_hot(ys, C).float(), gw, idx) / world
+    loss.backward()
+    ep.sync_gate_gradients()
+    torch.cuda.synchronize()
+    torch.save({"logits": logits.detach().cpu(), "rows": ep.last_rows, "idx": idx.cpu(),
+                "expert_grad": dense.experts[rank].classifier.weight.grad.cpu().clone(),
+                "gate_grad": dense.gate.vit.classifier.weight.grad.cpu().clone()}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sparse_expert_parallel_two_ranks_match_dense_on_gpu(tmp_path):
+    """SparseExpertParallelMoE (top-1 of 2 experts: each image travels to ONE rank, the expert there runs on the rows it received,
+    the logits travel back) on CUDA tensors against the dense model in this process"""
+    import torch.multiprocessing as mp
+    from touhouimageclassification_amd.ResMoE.model import make_ViTMoE
+    from touhouimageclassification_amd.ResMoE import train as mt
+    E, C, B = 2, 10, 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.start_processes(_sparse_ep_worker, args=(E, port, str(tmp_path)), nprocs=E, join=True, start_method="spawn")
+    torch.manual_seed(11)
+    dense = make_ViTMoE(num_classes=C, num_experts=E, top_k=1, gateway_t=0.01, pretrained=False, model_name="tiny", gate_pretrained=False,
+                        gate_model_name="tiny").to(DEV)
+    dense.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(E * B, 3, 224, 224, generator=g).to(DEV)
+    y = torch.randint(0, C, (E * B,), generator=g).to(DEV)
+    logits, gw, idx = dense(x)
+    loss = sum(mt.total_loss(logits[r * B:(r + 1) * B], torch.nn.functional.one_hot(y[r * B:(r + 1) * B], C).float(), gw[r * B:(r + 1) * B],
+                             idx[r * B:(r + 1) * B]) for r in range(E)) / E
+    loss.backward()
+    got = [torch.load(tmp_path / f"r{r}.pt") for r in range(E)]
+    assert [gt["rows"] for gt in got] == [int((idx == e).sum()) for e in range(E)] and sum(gt["rows"] for gt in got) == E * B
+    for r in range(E):
+        assert torch.equal(got[r]["idx"], idx[r * B:(r + 1) * B].cpu())
+        torch.testing.assert_close(got[r]["logits"], logits[r * B:(r + 1) * B].detach().cpu(), atol=2e-2, rtol=2e-2)   # different batch sizes: other tiles
+        ref = dense.experts[r].classifier.weight.grad.cpu()
+        hr.le(f"sparse EP expert {r} head gradient", float((got[r]["expert_grad"] - ref).norm()), 0.06 * float(ref.norm()) + 1e-6)
+        refg = dense.gate.vit.classifier.weight.grad.cpu() / E
+        hr.le(f"sparse EP gate gradient (rank {r})", float((got[r]["gate_grad"] - refg).norm()), 0.06 * float(refg.norm()) + 1e-6)
+
+
 # ---- a15: the augmentation presets on the GPU, as distributions ----------------------------------------------------------------
 def test_augmentation_presets_on_gpu_have_torchvision_statistics():
     """`GpuAugment` end to end (batched parameter sampling on the host + `tic_augment` on the GPU) on 1024 copies of one asymmetric

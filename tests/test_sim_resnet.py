@@ -45,7 +45,7 @@ def test_conv_ops_against_torch():
     # weight gradient layout round trip
     dwp = torch.randn(Co, Kp)
     gr = torch.ones(Co, Ci, k, k)
-    call("tic_conv_weight_grad", ptr(dwp), ptr(gr), Co, Ci, k, k, None)
+    call("tic_conv_weight_grad", ptr(dwp), ptr(gr), Co, Ci, k, k, 0, None)
     torch.testing.assert_close(gr - 1, dwp[:, :k * k * Ci].view(Co, k, k, Ci).permute(0, 3, 1, 2))
 
 

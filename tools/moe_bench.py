@@ -25,6 +25,7 @@ ap.add_argument("--model", default="google/vit-base-patch16-224")
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--sparse", action="store_true", help="every expert runs only on the samples routed to it (top-2 of E: 2/E of the dense work); N > 1: images travel only to their experts")
 a = ap.parse_args()
 if "WORLD_SIZE" not in os.environ and a.gpus > 1:   # our own ranks, before any GPU call
     with socket.socket() as s:
@@ -37,7 +38,7 @@ if "WORLD_SIZE" not in os.environ and a.gpus > 1:   # our own ranks, before any 
 
 import torch.distributed as dist  # noqa: E402
 from touhouimageclassification_amd.ResMoE import train as mt  # noqa: E402
-from touhouimageclassification_amd.ResMoE.model import ExpertParallelMoE, make_ViTMoE  # noqa: E402
+from touhouimageclassification_amd.ResMoE.model import ExpertParallelMoE, SparseExpertParallelMoE, make_ViTMoE  # noqa: E402
 
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
 dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -50,9 +51,10 @@ torch.manual_seed(11)   # every rank builds the same gate; rank r keeps expert r
 dense = make_ViTMoE(num_classes=a.classes, num_experts=a.experts if world == 1 else world, top_k=2, gateway_t=0.01, pretrained=False,
                     model_name=a.model, gate_pretrained=False, gate_model_name=a.model)
 if world == 1:
+    dense.sparse = a.sparse
     model = dense.to(dev)
 else:
-    model = ExpertParallelMoE(dense.experts[rank], dense.gate, a.classes).to(dev)
+    model = (SparseExpertParallelMoE if a.sparse else ExpertParallelMoE)(dense.experts[rank], dense.gate, a.classes).to(dev)
 model.train()
 opt = torch.optim.SGD(model.parameters(), lr=5e-2)   # TIC/ResMoE/train.py:176
 g = torch.Generator().manual_seed(5 + rank)
@@ -89,12 +91,13 @@ if world > 1:
 dt = dt.item() / a.steps
 if rank == 0:
     E = a.experts if world == 1 else world
-    # every expert sees every image of the (global) batch, the gate sees each image once: (E + 1) ViT-B training passes per image
-    fl = 105.38e9 * (E + 1)
+    # dense: every expert sees every image of the (global) batch, the gate sees each image once: (E + 1) ViT-B training passes per image;
+    # sparse: top-2 experts + the gate = 3 passes per image
+    fl = 105.38e9 * ((2 if a.sparse else E) + 1)
     ips = world * a.batch / dt
     print(json.dumps({"metric": "images/sec mixture of ViT experts train step (BASELINE config 5)", "value": round(ips, 1), "unit": "images/sec",
                       "n_gpus": world, "ms_per_step": round(dt * 1e3, 2), "loss": round(float(loss) * world, 4),
-                      "config": {"workload": f"gate ViT-B + {E} ViT-B experts, top-2, C={a.classes}, {'dense' if world == 1 else 'expert-parallel (1 expert per rank)'}",
+                      "config": {"workload": f"gate ViT-B + {E} ViT-B experts, top-2, C={a.classes}, {'sparse' if a.sparse else 'dense'}{'' if world == 1 else ', expert-parallel (1 expert per rank)'}",
                                  "per_rank_batch": a.batch, "optimizer": "SGD lr 5e-2"},
                       "tflops_per_gpu": round(ips * fl / world / 1e12, 1)}), flush=True)
 if world > 1:

@@ -15,7 +15,7 @@ gradients in backward).  Gate gradients are averaged over ranks; expert gradient
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist
@@ -105,15 +105,35 @@ class MoEClassifier(nn.Module):
     """Every expert is evaluated on every sample and the K routed ones are mixed by their gate weights (model.py:40-58: dense
     evaluation, sparse weights).  Returns ``(mixture logits [B,C], gate weights [B,E], top-k indices [B,K])``."""
 
-    def __init__(self, backbone, experts: nn.ModuleList, gate, top_k, num_classes):
+    def __init__(self, backbone, experts: nn.ModuleList, gate, top_k, num_classes, sparse: bool = False, pad_rows: int = 8):
         super().__init__()
         self.experts, self.top_k, self.num_classes = experts, top_k, num_classes
         self.shared_backbone, self.gate = backbone, gate
+        # sparse=True: every expert runs only on the samples routed to it (top_k / E of the dense work) -- the same mixture, because
+        # the reference multiplies the other experts' logits by gate weights that are exact zeros (model.py:53-57)
+        self.sparse, self.pad_rows = sparse, pad_rows
 
     def forward(self, x):
         feats = self.shared_backbone(x)
         gate_w, _, top_i = self.gate.route(x)
-        per_expert = torch.stack([ex(feats).logits for ex in self.experts], dim=0)     # [E, B, C], expert-major
+        if not self.sparse:
+            per_expert = torch.stack([ex(feats).logits for ex in self.experts], dim=0)     # [E, B, C], expert-major
+            return _CombineFn.apply(per_expert, gate_w, _backend_of(self.gate.vit)), gate_w, top_i
+        outs, where_e, where_s = [], [], []
+        for e, ex in enumerate(self.experts):
+            rows = (top_i == e).any(dim=1).nonzero().flatten()          # samples routed to expert e (one host sync per expert)
+            n = int(rows.numel())
+            if n == 0:
+                continue
+            sub = feats.index_select(0, rows)
+            n_pad = (n + self.pad_rows - 1) // self.pad_rows * self.pad_rows   # few distinct batch sizes for the engine's workspaces
+            if n_pad != n:
+                sub = torch.cat([sub, sub.new_zeros((n_pad - n,) + tuple(sub.shape[1:]))], 0)
+            outs.append(ex(sub).logits[:n])
+            where_e.append(torch.full_like(rows, e))
+            where_s.append(rows)
+        cat = torch.cat(outs, 0)
+        per_expert = cat.new_zeros((len(self.experts), x.shape[0], cat.shape[1])).index_put((torch.cat(where_e), torch.cat(where_s)), cat)
         return _CombineFn.apply(per_expert, gate_w, _backend_of(self.gate.vit)), gate_w, top_i
 
 
@@ -209,3 +229,87 @@ class ExpertParallelMoE(nn.Module):
             if p.grad is not None:
                 dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
                 p.grad.div_(w)
+
+
+# ---- sparse top-k dispatch ("or sparse ... 25 % of the dense FLOPs") ---------------------------------------------------
+def _exchange_rows(send: List[torch.Tensor], group) -> List[torch.Tensor]:
+    """all-to-all of row blocks with DIFFERENT row counts per (source, destination) pair: send[d] goes to rank d, the result's [s] came
+    from rank s.  RCCL: one `all_to_all` (xGMI is point-to-point: every pair's rows cross their own link).  gloo (CPU tests) has no
+    all-to-all: the counts are all-gathered and the payload travels as an all-gather of blocks padded to the largest count."""
+    w, r = dist.get_world_size(group), dist.get_rank(group)
+    dev = send[0].device
+    counts = torch.tensor([t.shape[0] for t in send], dtype=torch.int64, device=dev)
+    every = [torch.empty_like(counts) for _ in range(w)]
+    dist.all_gather(every, counts, group=group)
+    cm = torch.stack(every).cpu()                      # cm[s][d] = rows s sends to d  (one small host sync per exchange)
+    tail = send[0].shape[1:]
+    if dist.get_backend(group) != "gloo":
+        recv = [torch.empty((int(cm[s][r]),) + tuple(tail), dtype=send[0].dtype, device=dev) for s in range(w)]
+        dist.all_to_all(recv, [t.contiguous() for t in send], group=group)
+        return recv
+    mx = max(1, int(cm.max()))
+    block = torch.zeros((w, mx) + tuple(tail), dtype=send[0].dtype, device=dev)
+    for d in range(w):
+        block[d, :send[d].shape[0]] = send[d]
+    blocks = [torch.empty_like(block) for _ in range(w)]
+    dist.all_gather(blocks, block, group=group)
+    return [blocks[s][r, :int(cm[s][r])].clone() for s in range(w)]
+
+
+class _ReturnExpertRows(torch.autograd.Function):
+    """expert rank -> source ranks: the logits an expert computed for the rows it received travel back to where the rows came from;
+    backward sends the gradient of those logits the opposite way.  `splits` = rows received from each source (forward's send sizes)."""
+
+    @staticmethod
+    def forward(ctx, logits, splits, group):
+        ctx.group = group
+        out = _exchange_rows(list(logits.split(splits, 0)), group)
+        ctx.back_splits = [t.shape[0] for t in out]
+        return torch.cat(out, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        back = _exchange_rows(list(g.contiguous().split(ctx.back_splits, 0)), ctx.group)
+        return torch.cat(back, 0), None, None
+
+
+class SparseExpertParallelMoE(nn.Module):
+    """One expert per rank, SPARSE dispatch: a sample's image travels only to the `top_k` experts its gate routed it to, each expert
+    runs forward / backward on the rows it received (top_k / E of the dense work: 25 % for the reference's top-2 of 8), the K logit
+    rows travel back and are mixed with the gate weights.  Same results as the reference's dense evaluation
+    (`TIC/ResMoE/model.py:53-57` evaluates every expert on every sample and multiplies the non-routed ones by an exact 0): the
+    non-routed entries of the [E, b, C] tensor the combine kernel reads are zeros here, their weights are zeros there.
+    forward(x_local [b,3,H,W]) -> (mixture logits [b,C], gate weights [b,E], top-k indices [b,K]) as `MoEClassifier`."""
+
+    def __init__(self, expert: nn.Module, gate: GatingNetwork, num_classes: int, group=None, pad_rows: int = 8):
+        super().__init__()
+        self.expert, self.gate, self.num_classes, self.group, self.pad_rows = expert, gate, num_classes, group, pad_rows
+        self.last_rows = 0   # rows this rank's expert processed in the last forward (load-balance diagnostics)
+
+    def forward(self, x):
+        w = dist.get_world_size(self.group)
+        if self.gate.num_experts != w:
+            raise ValueError(f"expert parallelism places one expert per rank: {self.gate.num_experts} experts on {w} ranks")
+        b = x.shape[0]
+        gate_w, _, top_i = self.gate.route(x)                                  # [b,E] (zeros off the top-k), [b,K]
+        K = top_i.shape[1]
+        flat_e = top_i.reshape(-1)                                             # (sample s, slot k) -> expert
+        order = torch.argsort(flat_e, stable=True)                             # routed pairs grouped by destination expert
+        pair_sample = torch.div(order, K, rounding_mode="floor")
+        counts = torch.bincount(flat_e, minlength=w).tolist()
+        send = list(x.detach()[pair_sample].split(counts, 0))                  # images are data: no gradient travels back to them
+        recv = _exchange_rows(send, self.group)
+        splits = [t.shape[0] for t in recv]
+        rows = torch.cat(recv, 0)
+        n = rows.shape[0]
+        self.last_rows = n
+        n_pad = max(self.pad_rows, (n + self.pad_rows - 1) // self.pad_rows * self.pad_rows)   # few distinct batch sizes for the engine's workspaces
+        if n_pad != n:
+            rows = torch.cat([rows, rows.new_zeros((n_pad - n,) + tuple(rows.shape[1:]))], 0)
+        mine = self.expert(rows).logits[:n]                                    # this rank's expert on the rows routed to it
+        back = _ReturnExpertRows.apply(mine, splits, self.group)               # [b*K, C] in `order`
+        per_expert = back.new_zeros((w, b, back.shape[1]))
+        per_expert = per_expert.index_put((flat_e[order], pair_sample), back)  # [E, b, C], zeros where not routed
+        return _CombineFn.apply(per_expert, gate_w, _backend_of(self.gate.vit)), gate_w, top_i
+
+    sync_gate_gradients = ExpertParallelMoE.sync_gate_gradients

@@ -35,8 +35,13 @@ class _Conv(nn.Module):
         self.weight = nn.Parameter(w)
 
     @property
+    def stem(self) -> bool:
+        """the 3-channel 7x7 / 2 stem (TIC/ResNet/model.py:148): an implicit GEMM over the image padded to 4 channels (include/tic_hip.h)"""
+        return self.cin == 3 and self.k == 7 and self.stride == 2 and self.pad == 3
+
+    @property
     def kp(self):
-        return (self.k * self.k * self.cin + 63) // 64 * 64
+        return 256 if self.stem else (self.k * self.k * self.cin + 63) // 64 * 64
 
 
 class _BN(nn.Module):
@@ -135,8 +140,10 @@ class TicResNet(nn.Module):
     def _pack_variants(self, conv: _Conv):
         """which bf16 operand forms of a conv weight the step reads: [Cout, Kp] (0) always; for the input gradient either the flipped
         channel-transposed filter of the implicit GEMM (2) or the plain transpose (1)"""
+        if conv.stem:
+            return (3,)   # the stem layout; its input needs no gradient
         if conv is self.conv1:
-            return (0,)   # the stem's input needs no gradient
+            return (0,)
         return (0, 2) if (self._implicit(conv) and conv.stride == 1 and conv.cout % 64 == 0) else (0, 1)
 
     def _refresh_packs(self, dev):
@@ -153,7 +160,7 @@ class TicResNet(nn.Module):
             for c in convs:
                 packed = c.__dict__["_packed"] = {}
                 for t in self._pack_variants(c):
-                    shape = {0: (c.cout, c.kp), 1: (c.kp, c.cout), 2: (c.cin, c.k * c.k * c.cout)}[t]
+                    shape = {0: (c.cout, c.kp), 1: (c.kp, c.cout), 2: (c.cin, c.k * c.k * c.cout), 3: (c.cout, c.kp)}[t]
                     packed[t] = torch.empty(shape, dtype=torch.bfloat16, device=dev)
                     descs.append(struct.pack("<QQiiiiii", c.weight.data_ptr(), packed[t].data_ptr(), c.cout, c.cin, c.k, c.k, t, 0))
             st["n"] = len(descs)
@@ -170,7 +177,7 @@ class TicResNet(nn.Module):
     @staticmethod
     def _implicit(conv: _Conv) -> bool:
         # 3x3 convolutions and the strided 1x1 downsample projections (a 1x1 stride-1 conv is a plain GEMM on the activation)
-        return (conv.k > 1 or conv.stride > 1) and conv.cin % 64 == 0 and conv.cout % 8 == 0
+        return conv.stem or ((conv.k > 1 or conv.stride > 1) and conv.cin % 64 == 0 and conv.cout % 8 == 0)
 
     def _conv_fwd(self, conv: _Conv, x, B, H, W):
         """x [B,H,W,Cin] bf16 -> (y [M,Cout] bf16, col or None, Ho, Wo)"""
@@ -179,8 +186,8 @@ class TicResNet(nn.Module):
         M = B * Ho * Wo
         if self._implicit(conv):   # 3x3: gather inside the GEMM, no im2col buffer (the backward gathers again from x)
             y = torch.empty(M, conv.cout, dtype=torch.bfloat16, device=x.device)
-            self._call("tic_conv_igemm_fwd", x.data_ptr(), self._pack(conv, 0).data_ptr(), y.data_ptr(), B, H, W, conv.cin, conv.cout,
-                       conv.k, conv.k, conv.stride, conv.pad)
+            self._call("tic_conv_igemm_fwd", x.data_ptr(), self._pack(conv, 3 if conv.stem else 0).data_ptr(), y.data_ptr(), B, H, W,
+                       4 if conv.stem else conv.cin, conv.cout, conv.k, conv.k, conv.stride, conv.pad)   # stem: x is the 4-channel-padded image
             return y, x, Ho, Wo
         if conv.k == 1 and conv.stride == 1:
             col = x
@@ -260,8 +267,8 @@ class TicResNet(nn.Module):
         M = dy.shape[0]
         dw = conv.__dict__["_dw_view"]   # zeroed by _begin_backward
         if self._implicit(conv):   # col is the NHWC input itself
-            self._call("tic_conv_igemm_wgrad", dy.data_ptr(), col.data_ptr(), dw.data_ptr(), B, H, W, conv.cin, conv.cout, conv.k, conv.k,
-                       conv.stride, conv.pad)
+            self._call("tic_conv_igemm_wgrad", dy.data_ptr(), col.data_ptr(), dw.data_ptr(), B, H, W, 4 if conv.stem else conv.cin, conv.cout,
+                       conv.k, conv.k, conv.stride, conv.pad)
         else:
             self._call("tic_gemm_tn_bf16", dy.data_ptr(), col.data_ptr(), dw.data_ptr(), M, conv.cout, conv.kp)
         if not need_dx:   # (the fold of dw into the OIHW .grad happens for all convs at once, at the end of the backward)
@@ -403,8 +410,11 @@ class TicResNet(nn.Module):
         x = x.to(torch.float32).contiguous()
         self._refresh_packs(x.device)
         tape: Dict = {"B": B, "blocks": []}
-        xin = torch.empty(B, H, W, 3, dtype=torch.bfloat16, device=x.device)
-        self._call("tic_nchw_to_nhwc_bf16", x.data_ptr(), xin.data_ptr(), B, 3, H, W)
+        if self.conv1.stem and W % 2 == 0:   # 3 channels zero-padded to 4: 8-byte pixels, the stem convolution gathers them itself (no im2col)
+            xin = torch.empty(B, H, W, 4, dtype=torch.bfloat16, device=x.device)
+            self._call("tic_nchw_to_nhwc_pad_bf16", x.data_ptr(), xin.data_ptr(), B, 3, 4, H, W)
+        else:
+            raise ValueError("TIC HIP ResNet: the stem needs an even image width")
         c0, col0, H1, W1 = self._conv_fwd(self.conv1, xin, B, H, W)
         # bn1 -> relu -> maxpool in one piece: relu(bn(c0)) (411 MB at B = 256) is never stored; the backward needs c0, the batch
         # statistics and one byte of argmax position per pooled element
@@ -469,7 +479,8 @@ class TicResNet(nn.Module):
         ptrs = (tuple(self._grad_buf(c.weight).data_ptr() for c in convs), tuple(c.__dict__["_dw_view"].data_ptr() for c in convs), dev)
         st = self.__dict__.setdefault("_fold_state", {}).setdefault(stage, {})
         if st.get("ptrs") != ptrs:
-            descs = [struct.pack("<QQiiii", c.__dict__["_dw_view"].data_ptr(), self._grad_buf(c.weight).data_ptr(), c.cout, c.cin, c.k, c.k) for c in convs]
+            descs = [struct.pack("<QQiiiiii", c.__dict__["_dw_view"].data_ptr(), self._grad_buf(c.weight).data_ptr(), c.cout, c.cin, c.k, c.k,
+                                 3 if c.stem else 0, 0) for c in convs]
             st["n"] = len(descs)
             st["table"] = torch.frombuffer(bytearray(b"".join(descs)), dtype=torch.uint8).to(dev)
             st["ptrs"] = ptrs

@@ -76,12 +76,13 @@ SIGNATURES = {
     "tic_mix": ([P, P, I, I, I, I, I, F, I, I, I, I, P], I),
     "tic_mix_labels": ([P, P, I, I, F, P], I),
     "tic_conv_weight_pack": ([P, P, I, I, I, I, I, P], I),
-    "tic_conv_weight_grad": ([P, P, I, I, I, I, P], I),
+    "tic_conv_weight_grad": ([P, P, I, I, I, I, I, P], I),
     "tic_conv_weight_pack_many": ([P, I, P], I),
     "tic_conv_weight_grad_many": ([P, I, P], I),
     "tic_conv_igemm_fwd": ([P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_conv_igemm_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_nchw_to_nhwc_bf16": ([P, P, I, I, I, I, P], I),
+    "tic_nchw_to_nhwc_pad_bf16": ([P, P, I, I, I, I, I, P], I),
     "tic_im2col_bf16": ([P, P, I, I, I, I, I, I, I, I, P], I),
     "tic_col2im_bf16": ([P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_batchnorm_scratch_bytes": ([L, I], SZ),

@@ -18,8 +18,22 @@ struct ConvGeom {
 
 // OIHW fp32 -> [Co, Kp] bf16 with k = (ky*kw + kx)*Ci + c, zero padded; transposed == 1 writes [Kp, Co] (operand of the
 // explicit dgrad GEMM); transposed == 2 writes the implicit-GEMM dgrad filter [Ci][(ky', kx') * Co + o] = w[o][c][kh-1-ky'][kw-1-kx']
+// transposed == 3: the STEM layout of the implicit 7x7 / 2 convolution on a 4-channel-padded image (gemm.h): [Co][256] with
+// k = ky * 32 + px * 4 + c, px = kx + 1 in 1..7 (px 0 is the extra left pixel of the aligned 8-pixel window: weight 0), c < 3 (c = 3: the
+// padding channel), ky < 7 (row 7: zero)
+#define TIC_STEM_KP 256
 TIC_DEV void weight_ohwi_body(const float* __restrict__ w, bf16_t* __restrict__ out, int Co, const ConvGeom& g, int transposed) {
     const int taps = g.kh * g.kw;
+    if (transposed == 3) {
+        const long total3 = (long)Co * TIC_STEM_KP;
+        for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total3; i += (long)TIC_NBLK_X * 256) {
+            const int o = (int)(i / TIC_STEM_KP), k = (int)(i % TIC_STEM_KP), ky = k >> 5, px = (k >> 2) & 7, c = k & 3;
+            float v = 0.f;
+            if (ky < 7 && px >= 1 && c < 3) v = w[(((long)o * 3 + c) * 7 + ky) * 7 + (px - 1)];
+            out[i] = f2bf(v);
+        }
+        return;
+    }
     if (transposed == 2 && Co % 8 == 0) {   // [Ci][tap' * Co + o]: 8 consecutive o per thread, one 16-byte store
         const int oc = Co / 8;
         const long total2 = (long)g.Ci * taps * oc;
@@ -102,7 +116,7 @@ struct ConvPackDesc {   // = TicConvPackDesc (include/tic_hip.h)
 struct ConvGradDesc {   // = TicConvGradDesc
     const float* dw;
     float* grad;
-    int Co, Ci, kh, kw;
+    int Co, Ci, kh, kw, layout, pad_;   // layout 0: dw is [Co, Kp] tap-major; 3: the stem layout above ([Co, 256])
 };
 TIC_DEV ConvGeom weight_geom(int Ci, int kh, int kw) {
     ConvGeom g;
@@ -116,8 +130,19 @@ __global__ void __launch_bounds__(256) weight_ohwi_many_kernel(const ConvPackDes
     weight_ohwi_body(d.w, (bf16_t*)d.out, d.Co, weight_geom(d.Ci, d.kh, d.kw), d.transposed);
 }
 // grad OIHW fp32 += dW [Co, Kp] (tap-major)
-TIC_DEV void weight_grad_oihw_body(const float* __restrict__ dw, float* __restrict__ grad, int Co, const ConvGeom& g) {
+TIC_DEV void weight_grad_oihw_body(const float* __restrict__ dw, float* __restrict__ grad, int Co, const ConvGeom& g, int layout) {
     const long total = (long)Co * g.K;
+    if (layout == 3) {
+        for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
+            const int kx = (int)(i % 7);
+            long t = i / 7;
+            const int ky = (int)(t % 7);
+            t /= 7;
+            const int c = (int)(t % 3), o = (int)(t / 3);
+            grad[i] += dw[(long)o * TIC_STEM_KP + ky * 32 + (kx + 1) * 4 + c];
+        }
+        return;
+    }
     for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
         // i indexes the OIHW gradient
         const int kx = (int)(i % g.kw);
@@ -128,24 +153,24 @@ TIC_DEV void weight_grad_oihw_body(const float* __restrict__ dw, float* __restri
         grad[i] += dw[(long)o * g.Kp + (ky * g.kw + kx) * g.Ci + c];
     }
 }
-__global__ void __launch_bounds__(256) weight_grad_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int Co, ConvGeom g) {
-    weight_grad_oihw_body(dw, grad, Co, g);
+__global__ void __launch_bounds__(256) weight_grad_oihw_kernel(const float* __restrict__ dw, float* __restrict__ grad, int Co, ConvGeom g, int layout) {
+    weight_grad_oihw_body(dw, grad, Co, g, layout);
 }
 __global__ void __launch_bounds__(256) weight_grad_oihw_many_kernel(const ConvGradDesc* __restrict__ descs) {
     const ConvGradDesc d = descs[TIC_BID_Y];
-    weight_grad_oihw_body(d.dw, d.grad, d.Co, weight_geom(d.Ci, d.kh, d.kw));
+    weight_grad_oihw_body(d.dw, d.grad, d.Co, weight_geom(d.Ci, d.kh, d.kw), d.layout);
 }
 
-// x fp32 NCHW -> bf16 NHWC (the stem's input)
-__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B, int C, int H, int W) {
-    const long total = (long)B * H * W * C;
+// x fp32 NCHW -> bf16 NHWC with Cp >= C channels per pixel (the stem's input: Cp = 4, channel 3 = 0, so a pixel is 8 bytes)
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int B, int C, int Cp, int H, int W) {
+    const long total = (long)B * H * W * Cp;
     for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total; i += (long)TIC_NBLK_X * 256) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c = (int)(i % Cp);
+        long t = i / Cp;
         const int xx = (int)(t % W);
         t /= W;
         const int yy = (int)(t % H), b = (int)(t / H);
-        out[i] = f2bf(x[(((long)b * C + c) * H + yy) * W + xx]);
+        out[i] = c < C ? f2bf(x[(((long)b * C + c) * H + yy) * W + xx]) : f2bf(0.f);
     }
 }
 

@@ -230,6 +230,16 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
                 const int n = m / hw, rem = m - n * hw, oy = rem / p.cg.Wo, ox = rem - oy * p.cg.Wo;
                 iy0[i] = (m < p.M) ? oy * p.cg.stride - p.cg.pad : -(1 << 20);
                 ix0[i] = ox * p.cg.stride - p.cg.pad;
+                if (p.cg.Cin == 4) {
+                    // STEM (TIC/ResNet/model.py:148: 7x7 / 2, pad 3, on the 3-channel image zero-padded to 4 channels = 8 B per pixel).
+                    // A K tile of 64 = 2 filter rows x 8 pixels x 4 channels; the 8-pixel window starts at the EVEN pixel 2 ox - 4 (one
+                    // pixel left of the filter: weight 0), so every 16-byte chunk = 2 pixels is aligned and -- image widths being even --
+                    // entirely inside or entirely outside the image.  This lane's chunk: filter row 2 kt + (slot >> 2), pixels
+                    // 2 ox - 4 + 2 (slot & 3) (+1).  iy0 / ix0 hold THAT row / pixel for kt = 0.
+                    iy0[i] += (int)(slot_log >> 2);
+                    ix0[i] += -1 + 2 * (int)(slot_log & 3u);
+                    voa[i] = (uint32_t)((((long)n * p.cg.H + iy0[i]) * p.cg.W + ix0[i]) * 8);
+                } else
                 // 32-bit wrap is fine: the tap offset added in stage() brings every in-image address back into range
                 voa[i] = (uint32_t)((((long)n * p.cg.H + iy0[i]) * p.cg.W + ix0[i]) * p.cg.Cin * 2 + (long)slot_log * 16);
             } else {
@@ -241,6 +251,17 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
     auto stage = [&](int buf, int kt) {
         const uint32_t soff = (uint32_t)kt * (GEMM_BK * 2);
         const uint32_t base = (uint32_t)buf * GEMM_STAGE_BYTES;
+        if (CONV && p.cg.Cin == 4) {   // stem: filter rows 2 kt and 2 kt + 1 (row 7 does not exist: zero fill)
+            const uint32_t tapoff = (uint32_t)(2 * kt * p.cg.W * 8);
+            const int krow = 2 * kt + (int)((((uint32_t)(l & 7) ^ ((((uint32_t)l >> 4) & 3u) << 1))) >> 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool in = krow < 7 && (unsigned)(iy0[i] + 2 * kt) < (unsigned)p.cg.H && (unsigned)ix0[i] < (unsigned)p.cg.W;
+                glds16(ra, base + (uint32_t)(i * 4 + w) * 1024u, in ? voa[i] + tapoff : 0xFFFFFFF0u, 0);
+                glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, vob[i], soff);
+            }
+            return;
+        }
         if (CONV) {
             const int kk = kt * GEMM_BK, tap = kk / p.cg.Cin, c0 = kk - tap * p.cg.Cin;   // wave-uniform
             const int ky = tap / p.cg.KW, kx = tap - ky * p.cg.KW;
@@ -405,6 +426,11 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
         c_ky = tap / p.cg.KW;
         c_kx = tap - c_ky * p.cg.KW;
         c_choff = (uint32_t)((kcol - tap * p.cg.Cin) * 2);
+        if (p.cg.Cin == 4) {   // stem layout (see gemm_nt_kernel): k = ky * 32 + (pixel pair) * 8 + ...; pixel = 2 ox - 4 + 2 pair = ix0 - 1 + 2 pair
+            c_ky = kcol >> 5;
+            c_kx = -1 + 2 * ((kcol & 31) >> 3);
+            c_choff = 0;
+        }
         c_row = w * 4 + (int)rr;     // piece i adds 16 rows
         c_m = m_begin;
         inv_hw = 1.0f / (float)(p.cg.Ho * p.cg.Wo);
@@ -421,7 +447,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(GemmTnParams p) {
                 const int m = c_m + c_row + i * 16, hw = p.cg.Ho * p.cg.Wo;
                 const int n = div_small(m, hw, inv_hw), rem = m - n * hw, oy = div_small(rem, p.cg.Wo, inv_w), ox = rem - oy * p.cg.Wo;
                 const int iy = oy * p.cg.stride - p.cg.pad + c_ky, ix = ox * p.cg.stride - p.cg.pad + c_kx;
-                const bool in = b_ok && m < m_end && (unsigned)iy < (unsigned)p.cg.H && (unsigned)ix < (unsigned)p.cg.W;
+                const bool in = b_ok && m < m_end && (unsigned)iy < (unsigned)p.cg.H && (unsigned)ix < (unsigned)p.cg.W && (p.cg.Cin != 4 || c_ky < 7);   // (stem: filter row 7 is padding)
                 const uint32_t off = (uint32_t)((((long)n * p.cg.H + iy) * p.cg.W + ix) * p.cg.Cin * 2) + c_choff;
                 glds16(rb, base + 16384u + (uint32_t)(i * 4 + w) * 1024u, in ? off : 0xFFFFFFF0u, 0);
             } else {

@@ -807,10 +807,11 @@ static int conv_geom(ConvGeom& g, int B, int H, int W, int Ci, int kh, int kw, i
     return TIC_OK;
 }
 extern "C" int tic_conv_weight_pack(const float* w_oihw, void* w16, int Co, int Ci, int kh, int kw, int transposed, tic_stream_t stream) {
-    TIC_REQUIRE(w_oihw && w16 && Co >= 1 && transposed >= 0 && transposed <= 2, "conv_weight_pack: bad argument");
+    TIC_REQUIRE(w_oihw && w16 && Co >= 1 && transposed >= 0 && transposed <= 3, "conv_weight_pack: bad argument");
+    TIC_REQUIRE(transposed != 3 || (Ci == 3 && kh == 7 && kw == 7), "conv_weight_pack: layout 3 is the 3-channel 7x7 stem's");
     ConvGeom g;
     TIC_TRY(conv_geom(g, 1, kh, kw, Ci, kh, kw, 1, 0));
-    TIC_LAUNCH(weight_ohwi_kernel, ew_grid((long)Co * g.Kp), 256, 0, stream, w_oihw, (bf16_t*)w16, Co, g, transposed);
+    TIC_LAUNCH(weight_ohwi_kernel, ew_grid((long)Co * (transposed == 3 ? TIC_STEM_KP : g.Kp)), 256, 0, stream, w_oihw, (bf16_t*)w16, Co, g, transposed);
     return tic_after_launch("conv_weight_pack");
 }
 // the same for a whole network: `descs` is a table of n entries in DEVICE memory (built once by the caller), one launch
@@ -825,15 +826,20 @@ extern "C" int tic_conv_weight_grad_many(const TicConvGradDesc* descs, int n, ti
     TIC_LAUNCH(weight_grad_oihw_many_kernel, dim3(64, (unsigned)n), 256, 0, stream, (const ConvGradDesc*)descs);
     return tic_after_launch("conv_weight_grad_many");
 }
+// The 7x7 / 2 stem (TIC/ResNet/model.py:148) as an implicit GEMM: the image is NHWC with its 3 channels zero-padded to 4 (8 bytes per pixel,
+// tic_nchw_to_nhwc_pad_bf16), the filter is packed in layout 3 ([Cout, 256]: 7 rows x 8 pixels x 4 channels + a zero row), K = 256.
+#define TIC_CONV_IS_STEM(Cin, kh, kw, stride, pad) ((Cin) == 4 && (kh) == 7 && (kw) == 7 && (stride) == 2 && (pad) == 3)
 // implicit-GEMM convolution (3x3 and friends with Cin % 64 == 0): y[M = B*Ho*Wo, Cout] = gather(x) . Wpack^T
 extern "C" int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                                   int stride, int pad, tic_stream_t stream) {
     TIC_REQUIRE(x_nhwc && w_pack && y && B >= 1, "conv_igemm_fwd: bad argument");
-    TIC_REQUIRE(Cin % 64 == 0 && Cout % 8 == 0 && kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "conv_igemm_fwd: need Cin %% 64 == 0, Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    const bool stem = TIC_CONV_IS_STEM(Cin, kh, kw, stride, pad);
+    TIC_REQUIRE((Cin % 64 == 0 || stem) && Cout % 8 == 0 && kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "conv_igemm_fwd: need Cin %% 64 == 0 (or the 4-channel-padded 7x7/2 stem), Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    TIC_REQUIRE(!stem || W % 2 == 0, "conv_igemm_fwd: the stem form needs an even image width (16-byte pixel pairs)");
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     TIC_REQUIRE(Ho >= 1 && Wo >= 1, "conv_igemm_fwd: empty output");
     const long M = (long)B * Ho * Wo;
-    const int K = kh * kw * Cin;
+    const int K = stem ? TIC_STEM_KP : kh * kw * Cin;
     TIC_REQUIRE(M < (1L << 24) && (double)B * H * W * Cin * 2.0 < 4294967296.0 && (double)Cout * K * 2.0 < 4294967296.0,
                 "conv_igemm_fwd: tensor exceeds the 32-bit offset / 2^24 row range");
     GemmNtParams p;
@@ -849,11 +855,13 @@ extern "C" int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* 
 extern "C" int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* dw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                                     int stride, int pad, tic_stream_t stream) {
     TIC_REQUIRE(dy && x_nhwc && dw && B >= 1, "conv_igemm_wgrad: bad argument");
-    TIC_REQUIRE(Cin % 64 == 0 && Cout % 8 == 0 && kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "conv_igemm_wgrad: need Cin %% 64 == 0, Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    const bool stem = TIC_CONV_IS_STEM(Cin, kh, kw, stride, pad);
+    TIC_REQUIRE((Cin % 64 == 0 || stem) && Cout % 8 == 0 && kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0, "conv_igemm_wgrad: need Cin %% 64 == 0 (or the 4-channel-padded 7x7/2 stem), Cout %% 8 == 0 (Cin=%d Cout=%d)", Cin, Cout);
+    TIC_REQUIRE(!stem || W % 2 == 0, "conv_igemm_wgrad: the stem form needs an even image width");
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     TIC_REQUIRE(Ho >= 1 && Wo >= 1, "conv_igemm_wgrad: empty output");
     const long Ml = (long)B * Ho * Wo;
-    const int K = kh * kw * Cin, N = Cout;
+    const int K = stem ? TIC_STEM_KP : kh * kw * Cin, N = Cout;
     TIC_REQUIRE(Ml < (1L << 24) - 64 && (double)B * H * W * Cin * 2.0 < 4294967296.0 && ((double)Ml + 64.0) * Cout * 2.0 < 4294967296.0,
                 "conv_igemm_wgrad: tensor exceeds the 32-bit offset / 2^24 row range");
     const int M = (int)Ml;
@@ -872,17 +880,20 @@ extern "C" int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* d
     TIC_LAUNCH(gemm_tn_kernel<true>, dim3(tiles, split), 256, GEMM_LDS_BYTES, stream, p);
     return tic_after_launch("conv_igemm_wgrad");
 }
-extern "C" int tic_conv_weight_grad(const float* dw, float* grad_oihw, int Co, int Ci, int kh, int kw, tic_stream_t stream) {
-    TIC_REQUIRE(dw && grad_oihw && Co >= 1, "conv_weight_grad: bad argument");
+extern "C" int tic_conv_weight_grad(const float* dw, float* grad_oihw, int Co, int Ci, int kh, int kw, int layout, tic_stream_t stream) {
+    TIC_REQUIRE(dw && grad_oihw && Co >= 1 && (layout == 0 || (layout == 3 && Ci == 3 && kh == 7 && kw == 7)), "conv_weight_grad: bad argument");
     ConvGeom g;
     TIC_TRY(conv_geom(g, 1, kh, kw, Ci, kh, kw, 1, 0));
-    TIC_LAUNCH(weight_grad_oihw_kernel, ew_grid((long)Co * g.K), 256, 0, stream, dw, grad_oihw, Co, g);
+    TIC_LAUNCH(weight_grad_oihw_kernel, ew_grid((long)Co * g.K), 256, 0, stream, dw, grad_oihw, Co, g, layout);
     return tic_after_launch("conv_weight_grad");
 }
-extern "C" int tic_nchw_to_nhwc_bf16(const float* x, void* out, int B, int C, int H, int W, tic_stream_t stream) {
-    TIC_REQUIRE(x && out && B >= 1 && C >= 1, "nchw_to_nhwc: bad argument");
-    TIC_LAUNCH(nchw_to_nhwc_kernel, ew_grid((long)B * C * H * W), 256, 0, stream, x, (bf16_t*)out, B, C, H, W);
+extern "C" int tic_nchw_to_nhwc_pad_bf16(const float* x, void* out, int B, int C, int Cpad, int H, int W, tic_stream_t stream) {
+    TIC_REQUIRE(x && out && B >= 1 && C >= 1 && Cpad >= C, "nchw_to_nhwc: bad argument");
+    TIC_LAUNCH(nchw_to_nhwc_kernel, ew_grid((long)B * Cpad * H * W), 256, 0, stream, x, (bf16_t*)out, B, C, Cpad, H, W);
     return tic_after_launch("nchw_to_nhwc");
+}
+extern "C" int tic_nchw_to_nhwc_bf16(const float* x, void* out, int B, int C, int H, int W, tic_stream_t stream) {
+    return tic_nchw_to_nhwc_pad_bf16(x, out, B, C, C, H, W, stream);
 }
 extern "C" int tic_im2col_bf16(const void* x, void* col, int B, int H, int W, int Ci, int kh, int kw, int stride, int pad, tic_stream_t stream) {
     TIC_REQUIRE(x && col, "im2col: null pointer");
