@@ -194,6 +194,14 @@ int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* y, int B, i
                        int stride, int pad, tic_stream_t stream);
 int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* dw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                          int stride, int pad, tic_stream_t stream);
+/* Input gradient of a stride-2 convolution (3x3 pad 1 -- the first block of a stage, model.py:87 -- or the 1x1 downsample projection, :193-197)
+ * without a column buffer / col2im pass: the input pixels of parity class (py, px) = (row & 1, column & 1) see (1 + py)(1 + px) of the 9 taps
+ * (k = 3), or the one tap when py = px = 0 (k = 1: the other classes get no gradient), so every class is a stride-1 implicit GEMM over dY
+ * [B, H/2, W/2, Cout] whose rows are stored at (2a + py, 2b + px) of dx [B, H, W, Cin].  One call per class.  w_class =
+ * tic_conv_weight_pack(..., transposed = 4 + 2 py + px) for k = 3 ([Cin][(ky', kx') * Cout + o] over the class's taps), transposed = 2 for
+ * k = 1.  accumulate != 0: dx rows of the class += the product (as TIC_EPI_ADDAUX); rows of other classes are never touched.  H, W even. */
+int tic_conv_igemm_dgrad_s2(const void* dy, const void* w_class, void* dx, int B, int H, int W, int Cin, int Cout, int k, int py, int px,
+                            int accumulate, tic_stream_t stream);
 /* The 7x7 / 2, pad 3 stem (model.py:148) is an implicit GEMM too: pass the image as NHWC with 4 channels per pixel (tic_nchw_to_nhwc_pad_bf16,
  * Cpad = 4: 8-byte pixels, so the aligned 8-pixel window of a filter row is four 16-byte chunks), Cin = 4, kh = kw = 7, stride 2, pad 3, an even
  * W, and w_pack / dw in layout 3 ([Cout, 256]).  No im2col buffer (1.2 GB at 256 images) is written or read. */

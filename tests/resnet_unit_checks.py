@@ -83,7 +83,8 @@ class _Harness:
         for c in (m for top in mods for m in top.modules() if isinstance(m, self.rm._Conv)):
             packed = c.__dict__["_packed"] = {}
             for t in host._pack_variants(c):
-                shape = {0: (c.cout, c.kp), 1: (c.kp, c.cout), 2: (c.cin, c.k * c.k * c.cout), 3: (c.cout, c.kp)}[t]
+                shape = {0: (c.cout, c.kp), 1: (c.kp, c.cout), 2: (c.cin, c.k * c.k * c.cout), 3: (c.cout, c.kp), 4: (c.cin, c.cout), 5: (c.cin, 2 * c.cout),
+                         6: (c.cin, 2 * c.cout), 7: (c.cin, 4 * c.cout)}[t]
                 packed[t] = torch.empty(shape, dtype=torch.bfloat16, device=dev)
                 host._call("tic_conv_weight_pack", c.weight.data_ptr(), packed[t].data_ptr(), c.cout, c.cin, c.k, c.k, t)
             c.__dict__["_dw_view"] = torch.zeros(c.cout * c.kp, device=dev)

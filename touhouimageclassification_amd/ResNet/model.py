@@ -3,9 +3,12 @@ num_classes=1000, **kw)`` returning an ``nn.Module`` that maps ``[B,3,H,W]`` fp3
 (TIC/ResNet/model.py:249-276, used at TIC/ResNet/train.py:52,239), with the reference's ``state_dict`` keys
 (conv1.weight, bn1.{weight,bias,running_mean,running_var,num_batches_tracked}, layerN.i.convK/bnK/downsample.{0,1}, fc.*).
 
-Forward and backward run in libtic_hip.so: NHWC bf16 activations, every convolution a bf16 MFMA GEMM (1x1 stride-1
-directly on the activation, the rest through im2col), train-mode BatchNorm (+ReLU, +residual) / pools as HIP kernels,
-fp32 master weights and fp32 gradient accumulation.  Blocks follow model.py:17-63 (BasicBlock) and :66-115
+Forward and backward run in libtic_hip.so: NHWC bf16 activations, every convolution an implicit bf16 MFMA GEMM -- 1x1 stride-1
+directly on the activation; 3x3, strided 1x1 and the 7x7 stem (image padded to 4 channels) gather their operand inside the GEMM;
+stride-2 input gradients run as one small implicit GEMM per parity class of the input pixels -- no im2col / col2im buffer anywhere
+on the ResNet-18 ... 152 paths (the explicit im2col route remains only for channel counts that are not multiples of 64);
+train-mode BatchNorm (+ReLU, +residual) / pools as HIP kernels, fp32 master weights and fp32 gradient accumulation.
+Blocks follow model.py:17-63 (BasicBlock) and :66-115
 (Bottleneck, stride on the 3x3), stages / downsample follow ``_make_layer`` :185-208, init follows :168-183.
 """
 from __future__ import annotations
@@ -144,6 +147,8 @@ class TicResNet(nn.Module):
             return (3,)   # the stem layout; its input needs no gradient
         if conv is self.conv1:
             return (0,)
+        if self._s2_dgrad(conv):   # stride 2: one filter per parity class of the input gradient (3x3: four of them; 1x1: the flipped filter itself)
+            return (0, 4, 5, 6, 7) if conv.k == 3 else (0, 2)
         return (0, 2) if (self._implicit(conv) and conv.stride == 1 and conv.cout % 64 == 0) else (0, 1)
 
     def _refresh_packs(self, dev):
@@ -160,7 +165,8 @@ class TicResNet(nn.Module):
             for c in convs:
                 packed = c.__dict__["_packed"] = {}
                 for t in self._pack_variants(c):
-                    shape = {0: (c.cout, c.kp), 1: (c.kp, c.cout), 2: (c.cin, c.k * c.k * c.cout), 3: (c.cout, c.kp)}[t]
+                    shape = {0: (c.cout, c.kp), 1: (c.kp, c.cout), 2: (c.cin, c.k * c.k * c.cout), 3: (c.cout, c.kp), 4: (c.cin, c.cout),
+                             5: (c.cin, 2 * c.cout), 6: (c.cin, 2 * c.cout), 7: (c.cin, 4 * c.cout)}[t]
                     packed[t] = torch.empty(shape, dtype=torch.bfloat16, device=dev)
                     descs.append(struct.pack("<QQiiiiii", c.weight.data_ptr(), packed[t].data_ptr(), c.cout, c.cin, c.k, c.k, t, 0))
             st["n"] = len(descs)
@@ -173,6 +179,12 @@ class TicResNet(nn.Module):
         """bf16 GEMM operand of a conv weight ([Cout, Kp], its transpose (1), or the flipped channel-transposed filter of the
         implicit-GEMM input gradient (2)); kept fresh by _refresh_packs at the start of every forward"""
         return conv.__dict__["_packed"][int(transposed)]
+
+    @staticmethod
+    def _s2_dgrad(conv: _Conv) -> bool:
+        """stride-2 convolutions whose input gradient runs as parity-class implicit GEMMs (tic_conv_igemm_dgrad_s2): the 3x3 / pad 1 of a
+        stage's first block and the 1x1 downsample projection (TIC/ResNet/model.py:87, 193-197)"""
+        return conv.stride == 2 and conv.cout % 64 == 0 and conv.cin % 8 == 0 and ((conv.k == 3 and conv.pad == 1) or (conv.k == 1 and conv.pad == 0))
 
     @staticmethod
     def _implicit(conv: _Conv) -> bool:
@@ -280,6 +292,15 @@ class TicResNet(nn.Module):
             dx = torch.empty(B * H * W, conv.cin, dtype=torch.bfloat16, device=dy.device)
             self._call("tic_conv_igemm_fwd", dy.data_ptr(), self._pack(conv, 2).data_ptr(), dx.data_ptr(), B, Ho, Wo, conv.cout, conv.cin,
                        conv.k, conv.k, 1, conv.k - 1 - conv.pad)
+            return dx
+        if self._s2_dgrad(conv) and H % 2 == 0 and W % 2 == 0:
+            # stride 2: every parity class of the input pixels is its own small implicit GEMM over dY, stored (or added) in place
+            acc = dx_accumulate_into is not None
+            # (a 1x1 / 2 projection reaches the even pixels only: a fresh buffer starts at zero; the model always accumulates there)
+            dx = dx_accumulate_into if acc else (torch.empty if conv.k == 3 else torch.zeros)(B * H * W, conv.cin, dtype=torch.bfloat16, device=dy.device)
+            for py, px in (((0, 0), (0, 1), (1, 0), (1, 1)) if conv.k == 3 else ((0, 0),)):
+                wpk = self._pack(conv, 4 + 2 * py + px if conv.k == 3 else 2)
+                self._call("tic_conv_igemm_dgrad_s2", dy.data_ptr(), wpk.data_ptr(), dx.data_ptr(), B, H, W, conv.cin, conv.cout, conv.k, py, px, 1 if acc else 0)
             return dx
         if conv.k == 1 and conv.stride == 1:   # the activation gradient IS the GEMM output; an accumulation target rides in its epilogue
             return self._gemm_nt(dy, self._pack(conv, 1), M, conv.kp, conv.cout, add_into=dx_accumulate_into)

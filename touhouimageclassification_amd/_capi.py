@@ -80,6 +80,7 @@ SIGNATURES = {
     "tic_conv_weight_pack_many": ([P, I, P], I),
     "tic_conv_weight_grad_many": ([P, I, P], I),
     "tic_conv_igemm_fwd": ([P, P, P, I, I, I, I, I, I, I, I, I, P], I),
+    "tic_conv_igemm_dgrad_s2": ([P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_conv_igemm_wgrad": ([P, P, P, I, I, I, I, I, I, I, I, I, P], I),
     "tic_nchw_to_nhwc_bf16": ([P, P, I, I, I, I, P], I),
     "tic_nchw_to_nhwc_pad_bf16": ([P, P, I, I, I, I, I, P], I),

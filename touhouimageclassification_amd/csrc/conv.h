@@ -22,8 +22,24 @@ struct ConvGeom {
 // k = ky * 32 + px * 4 + c, px = kx + 1 in 1..7 (px 0 is the extra left pixel of the aligned 8-pixel window: weight 0), c < 3 (c = 3: the
 // padding channel), ky < 7 (row 7: zero)
 #define TIC_STEM_KP 256
+// transposed == 4 + 2 py + px (3x3 filters): the filter of ONE parity class of the stride-2 input gradient (tic_conv_igemm_dgrad_s2):
+// dx[2a + py][2b + px] = sum over the taps ky = py ? {2, 0} : {1}, kx likewise, of dy[a + ky'][b + kx'] . w[:, :, ky, kx], with ky' = 0 for
+// ky = 2 or 1 and ky' = 1 for ky = 0.  Layout [Ci][(ky' * kw' + kx') * Co + o], kh' = 1 + py, kw' = 1 + px: 1, 2, 2 and 4 of the 9 taps.
 TIC_DEV void weight_ohwi_body(const float* __restrict__ w, bf16_t* __restrict__ out, int Co, const ConvGeom& g, int transposed) {
     const int taps = g.kh * g.kw;
+    if (transposed >= 4 && transposed <= 7) {
+        const int py = (transposed - 4) >> 1, px = (transposed - 4) & 1, kwp = 1 + px, tp = (1 + py) * kwp;
+        const long total4 = (long)g.Ci * tp * Co;
+        for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total4; i += (long)TIC_NBLK_X * 256) {
+            const int o = (int)(i % Co);
+            long t = i / Co;
+            const int tap = (int)(t % tp), c = (int)(t / tp);
+            const int kyp = tap / kwp, kxp = tap - kyp * kwp;
+            const int ky = py ? (kyp == 0 ? 2 : 0) : 1, kx = px ? (kxp == 0 ? 2 : 0) : 1;
+            out[i] = f2bf(w[(((long)o * g.Ci + c) * 3 + ky) * 3 + kx]);
+        }
+        return;
+    }
     if (transposed == 3) {
         const long total3 = (long)Co * TIC_STEM_KP;
         for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < total3; i += (long)TIC_NBLK_X * 256) {

@@ -24,6 +24,9 @@
 // filter, its stride-1 input gradient.
 struct ConvGather {
     int H, W, Cin, Ho, Wo, KW, stride, pad;
+    // output-row remap (rm_W > 0): GEMM row m = (image, a, b) of the Ho x Wo grid is stored at row (image, 2a + rm_py, 2b + rm_px) of an
+    // rm_H x rm_W image -- one parity class of the input gradient of a stride-2 convolution (tic_conv_igemm_dgrad_s2)
+    int rm_H, rm_W, rm_py, rm_px;
 };
 struct GemmNtParams {
     const bf16_t* A;   // [M,K]  (CONV: the NHWC activation [B,H,W,Cin])
@@ -347,6 +350,21 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
         }
     }
     // ---- epilogue: lane holds rows m = ..+(l&15), 4 consecutive n = ..+4(l>>4) ------------------------
+    if (CONV && p.cg.rm_W > 0) {   // rows land in one parity class of a larger image (kernel argument: uniform)
+        GemmNtParams q = p;
+        const int hw = p.cg.Ho * p.cg.Wo;
+        q.M = (p.M / hw) * p.cg.rm_H * p.cg.rm_W;
+        gemm_epilogue<EPI, 4, 4>(
+            q,
+            [&](int r) {
+                const int m = m0 + wm * 64 + r * 16 + (l & 15);
+                if (m >= p.M) return 0x7fffffff;
+                const int img = m / hw, rem = m - img * hw, a = rem / p.cg.Wo, b = rem - a * p.cg.Wo;
+                return (img * p.cg.rm_H + 2 * a + p.cg.rm_py) * p.cg.rm_W + 2 * b + p.cg.rm_px;
+            },
+            [&](int g) { return n0 + wn * 64 + g * 16 + 4 * (l >> 4); }, [&](int r, int g) { return acc[r][g]; });
+        return;
+    }
     gemm_epilogue<EPI, 4, 4>(
         p, [&](int r) { return m0 + wm * 64 + r * 16 + (l & 15); }, [&](int g) { return n0 + wn * 64 + g * 16 + 4 * (l >> 4); },
         [&](int r, int g) { return acc[r][g]; });

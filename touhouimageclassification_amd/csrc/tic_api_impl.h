@@ -807,8 +807,9 @@ static int conv_geom(ConvGeom& g, int B, int H, int W, int Ci, int kh, int kw, i
     return TIC_OK;
 }
 extern "C" int tic_conv_weight_pack(const float* w_oihw, void* w16, int Co, int Ci, int kh, int kw, int transposed, tic_stream_t stream) {
-    TIC_REQUIRE(w_oihw && w16 && Co >= 1 && transposed >= 0 && transposed <= 3, "conv_weight_pack: bad argument");
+    TIC_REQUIRE(w_oihw && w16 && Co >= 1 && transposed >= 0 && transposed <= 7, "conv_weight_pack: bad argument");
     TIC_REQUIRE(transposed != 3 || (Ci == 3 && kh == 7 && kw == 7), "conv_weight_pack: layout 3 is the 3-channel 7x7 stem's");
+    TIC_REQUIRE(transposed < 4 || (kh == 3 && kw == 3), "conv_weight_pack: layouts 4..7 are the parity classes of a 3x3 stride-2 input gradient");
     ConvGeom g;
     TIC_TRY(conv_geom(g, 1, kh, kw, Ci, kh, kw, 1, 0));
     TIC_LAUNCH(weight_ohwi_kernel, ew_grid((long)Co * (transposed == 3 ? TIC_STEM_KP : g.Kp)), 256, 0, stream, w_oihw, (bf16_t*)w16, Co, g, transposed);
@@ -850,6 +851,36 @@ extern "C" int tic_conv_igemm_fwd(const void* x_nhwc, const void* w_pack, void* 
     TIC_RT_MAX_LDS((gemm_nt_kernel<TIC_EPI_BF16, true>), GEMM_LDS_BYTES);
     TIC_LAUNCH((gemm_nt_kernel<TIC_EPI_BF16, true>), grid, 256, GEMM_LDS_BYTES, stream, p);
     return tic_after_launch("conv_igemm_fwd");
+}
+// Input gradient of a STRIDE-2 convolution (3x3 pad 1: Bottleneck conv2 / BasicBlock conv1 of a stage's first block, model.py:87; 1x1 pad 0: the
+// downsample projection, :193-197) without a column buffer or a col2im pass: the input pixels of parity class (py, px) receive contributions from
+// (1 + py)(1 + px) of the 9 taps only (k = 3) or from the single tap when py = px = 0 (k = 1), so each class is a small stride-1 implicit GEMM over dY
+// whose rows are stored at (2a + py, 2b + px).  One call = one class; w_class = tic_conv_weight_pack(..., transposed = 4 + 2 py + px) for k = 3,
+// transposed = 2 for k = 1.  accumulate != 0: dx rows of the class += (TIC_EPI_ADDAUX semantics), the other classes are not touched.
+extern "C" int tic_conv_igemm_dgrad_s2(const void* dy, const void* w_class, void* dx, int B, int H, int W, int Cin, int Cout, int k, int py, int px,
+                                       int accumulate, tic_stream_t stream) {
+    TIC_REQUIRE(dy && w_class && dx && B >= 1, "conv_igemm_dgrad_s2: bad argument");
+    TIC_REQUIRE((k == 3 || (k == 1 && py == 0 && px == 0)) && (py | 1) == 1 && (px | 1) == 1, "conv_igemm_dgrad_s2: k = 3 with py, px in {0, 1}, or k = 1 with py = px = 0");
+    TIC_REQUIRE(H % 2 == 0 && W % 2 == 0 && Cout % 64 == 0 && Cin % 8 == 0, "conv_igemm_dgrad_s2: need even H, W, Cout %% 64 == 0, Cin %% 8 == 0 (H=%d W=%d Cin=%d Cout=%d)", H, W, Cin, Cout);
+    const int Hs = H / 2, Ws = W / 2, khp = (k == 3) ? 1 + py : 1, kwp = (k == 3) ? 1 + px : 1;
+    const long M = (long)B * Hs * Ws;
+    const int K = khp * kwp * Cout;
+    TIC_REQUIRE(M < (1L << 24) && (double)B * H * W * Cin * 2.0 < 4294967296.0 && (double)Cin * K * 2.0 < 4294967296.0,
+                "conv_igemm_dgrad_s2: tensor exceeds the 32-bit offset / 2^24 row range");
+    GemmNtParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = (const bf16_t*)dy; p.B = (const bf16_t*)w_class; p.M = (int)M; p.N = Cin; p.K = K; p.out = (bf16_t*)dx; p.aux = (const bf16_t*)dx;
+    p.cg.H = Hs; p.cg.W = Ws; p.cg.Cin = Cout; p.cg.Ho = Hs; p.cg.Wo = Ws; p.cg.KW = kwp; p.cg.stride = 1; p.cg.pad = 0;   // dY is the "image": Ho x Wo = H/2 x W/2
+    p.cg.rm_H = H; p.cg.rm_W = W; p.cg.rm_py = py; p.cg.rm_px = px;
+    const int grid = (int)(((M + 127) / 128) * ((Cin + 127) / 128));
+    if (accumulate) {
+        TIC_RT_MAX_LDS((gemm_nt_kernel<TIC_EPI_ADDAUX, true>), GEMM_LDS_BYTES);
+        TIC_LAUNCH((gemm_nt_kernel<TIC_EPI_ADDAUX, true>), grid, 256, GEMM_LDS_BYTES, stream, p);
+    } else {
+        TIC_RT_MAX_LDS((gemm_nt_kernel<TIC_EPI_BF16, true>), GEMM_LDS_BYTES);
+        TIC_LAUNCH((gemm_nt_kernel<TIC_EPI_BF16, true>), grid, 256, GEMM_LDS_BYTES, stream, p);
+    }
+    return tic_after_launch("conv_igemm_dgrad_s2");
 }
 // dW[Cout, kh*kw*Cin] (fp32, tap-major) += dY[M, Cout]^T . gather(x)   -- the weight gradient without an im2col buffer
 extern "C" int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* dw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
