@@ -350,19 +350,33 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
         }
     }
     // ---- epilogue: lane holds rows m = ..+(l&15), 4 consecutive n = ..+4(l>>4) ------------------------
+    int drow[4];   // destination row of this lane's 4 accumulator rows
+#pragma unroll
+    for (int r = 0; r < 4; ++r) drow[r] = m0 + wm * 64 + r * 16 + (l & 15);
+    int m_lim = p.M;
     if (CONV && p.cg.rm_W > 0) {   // rows land in one parity class of a larger image (kernel argument: uniform)
-        GemmNtParams q = p;
         const int hw = p.cg.Ho * p.cg.Wo;
-        q.M = (p.M / hw) * p.cg.rm_H * p.cg.rm_W;
+        const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)p.cg.Wo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = drow[r];
+            const int img = (int)((float)m * inv_hw + 0.5f * inv_hw), rem = m - img * hw;   // exact for m < 2^24 up to the corrections below
+            int im = img, rm = rem;
+            if (rm < 0) { --im; rm += hw; }
+            if (rm >= hw) { ++im; rm -= hw; }
+            int a = (int)((float)rm * inv_w);
+            if (a * p.cg.Wo > rm) --a;
+            if ((a + 1) * p.cg.Wo <= rm) ++a;
+            const int b = rm - a * p.cg.Wo;
+            drow[r] = m < p.M ? (im * p.cg.rm_H + 2 * a + p.cg.rm_py) * p.cg.rm_W + 2 * b + p.cg.rm_px : 0x7fffffff;
+        }
+        m_lim = (p.M / hw) * p.cg.rm_H * p.cg.rm_W;
+    }
+    if (CONV) {
+        GemmNtParams q = p;
+        q.M = m_lim;
         gemm_epilogue<EPI, 4, 4>(
-            q,
-            [&](int r) {
-                const int m = m0 + wm * 64 + r * 16 + (l & 15);
-                if (m >= p.M) return 0x7fffffff;
-                const int img = m / hw, rem = m - img * hw, a = rem / p.cg.Wo, b = rem - a * p.cg.Wo;
-                return (img * p.cg.rm_H + 2 * a + p.cg.rm_py) * p.cg.rm_W + 2 * b + p.cg.rm_px;
-            },
-            [&](int g) { return n0 + wn * 64 + g * 16 + 4 * (l >> 4); }, [&](int r, int g) { return acc[r][g]; });
+            q, [&](int r) { return drow[r]; }, [&](int g) { return n0 + wn * 64 + g * 16 + 4 * (l >> 4); }, [&](int r, int g) { return acc[r][g]; });
         return;
     }
     gemm_epilogue<EPI, 4, 4>(
