@@ -307,6 +307,12 @@ typedef struct {
 /* refresh the bf16 GEMM operands from params (after load_state_dict or an external optimizer step);
  * transposes_only != 0 when w16 is already current (tic_adamw wrote it) and only wT16 needs rebuilding */
 int tic_vit_refresh_weights(const TicVitState* st, int transposes_only, tic_stream_t stream);
+/* AdamW over the replica's flat buffers (the arithmetic of tic_adamw, bit for bit) that ALSO writes both bf16 operand copies in the same
+ * pass: the Linear matrices leave their 64x64 tiles as w16 and, through an LDS transpose, as wT16; biases / LayerNorm / embeddings / head
+ * follow the flat rule.  m, v: flat fp32 moment buffers in the parameter layout.  After it tic_vit_refresh_weights has nothing left to do
+ * (saves the per-step 1.2 GB + 0.6 GB cast + transpose pass of ViT-L).  optim.FusedAdamW, full fine-tuning. */
+int tic_vit_adamw(const TicVitState* st, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  tic_stream_t stream);
 /* pixel_values [B,3,224,224] fp32 -> logits [B,C] fp32 (also kept in the workspace) */
 int tic_vit_forward(const TicVitState* st, const float* pixel_values, float* logits_out, tic_stream_t stream);
 /* the same forward when NO backward will follow (validate_step / serve / full_judge under torch.no_grad): fc1 stores only gelu(u),

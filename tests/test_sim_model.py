@@ -174,3 +174,31 @@ def test_inference_forward_equals_training_forward_and_refuses_backward(golden_d
         e.backward(torch.zeros_like(infer_logits))
     logits = m(x).logits   # a training forward at the same batch size clears the mark
     logits.sum().backward()
+
+
+def test_fused_adamw_writes_both_operand_copies_and_equals_the_flat_rule():
+    """`FusedAdamW.step` on a fully trainable model = `tic_vit_adamw`: the fp32 update of the flat rule (`tic_adamw`, itself checked against
+    torch.optim.AdamW) bit for bit, with w16 AND the transposed copies written in the same pass -- the next forward refreshes nothing."""
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from tests.simlib import call
+    torch.manual_seed(3)
+    m = ViT(10, pretrained=False, model_name="tiny", backend=SimBackend())
+    e = m._engine
+    x, y = torch.randn(2, 3, 224, 224), torch.tensor([3, 7])
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=0.01)
+    ref_p, ref_m, ref_v = e.params.clone(), torch.zeros_like(e.params), torch.zeros_like(e.params)
+    for step in (1, 2):
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m(x).logits, y).backward()
+        grads = e.grads.clone()
+        opt.step()
+        call("tic_adamw", ref_p.data_ptr(), grads.data_ptr(), ref_m.data_ptr(), ref_v.data_ptr(), None, ref_p.numel(), 1e-3, 0.9, 0.999, 1e-8, 0.01, step, None)
+        assert torch.equal(e.params, ref_p) and torch.equal(opt._m, ref_m) and torch.equal(opt._v, ref_v)
+        assert e._weights_version == e._version()          # clean: the forward below must not launch a refresh ...
+        kc.check_refresh_weights(m)                         # ... and both bf16 copies are already bf16(W) / its transposes
+    refreshed = []
+    orig = e.backend.call
+    e.backend.call = lambda name, *a: (refreshed.append(name), orig(name, *a))[1]
+    with torch.no_grad():
+        m(x)
+    assert "tic_vit_refresh_weights" not in refreshed and "tic_vit_forward_infer" in refreshed

@@ -105,6 +105,7 @@ SIGNATURES = {
     "tic_moe_loss": ([P, P, P, P, P, P, I, I, I, F, F, F, P], I),
     "tic_vit_layout": ([C.POINTER(TicVitDims), C.POINTER(TicVitLayout)], I),
     "tic_vit_refresh_weights": ([C.POINTER(TicVitState), I, P], I),
+    "tic_vit_adamw": ([C.POINTER(TicVitState), P, P, F, F, F, F, F, I, P], I),
     "tic_vit_forward": ([C.POINTER(TicVitState), P, P, P], I),
     "tic_vit_forward_infer": ([C.POINTER(TicVitState), P, P, P], I),
     "tic_vit_backward_head": ([C.POINTER(TicVitState), P, P], I),

@@ -165,6 +165,91 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// AdamW of the four Linear weight matrices of every transformer block, tile by tile: the update is the flat kernel's, and the tile that is
+// in registers anyway also leaves as BOTH bf16 operand forms the next step's GEMMs read -- w16 (row-major, forward / dW) and wT16 (transposed,
+// the dX GEMMs) -- so the per-step cast + transpose pass over the fp32 weights (1.2 GB read + 0.6 GB written for ViT-L) disappears.
+// Grid (tiles per layer, layers) as cast_transpose_group_kernel; a 64 x 64 tile = 256 threads x 2 trips x (2 rows x 4 columns).
+struct AdamwHyper {
+    float lr, b1, b2, eps, wd, inv_bc1, inv_sqrt_bc2;
+};
+TIC_DEV void adamw4(f32x4& pv, const f32x4& gv, f32x4& mv, f32x4& vv, const AdamwHyper& h) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // the same expression order as adamw_kernel: bit-identical parameters
+        pv[r] *= (1.0f - h.lr * h.wd);
+        mv[r] = h.b1 * mv[r] + (1.0f - h.b1) * gv[r];
+        vv[r] = h.b2 * vv[r] + (1.0f - h.b2) * gv[r] * gv[r];
+        const float denom = sqrtf(vv[r]) * h.inv_sqrt_bc2 + h.eps;
+        pv[r] -= (h.lr * h.inv_bc1) * (mv[r] / denom);
+    }
+}
+__global__ void __launch_bounds__(256) adamw_tiles_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                           bf16_t* __restrict__ w16, bf16_t* __restrict__ wT, CastTransposeGroup gp, AdamwHyper h) {
+    int tile = TIC_BID_X, which = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (TIC_BID_X >= gp.tile_end[i]) {
+            which = i + 1;
+            tile = TIC_BID_X - gp.tile_end[i];
+        }
+    const int R = gp.R[which], C = gp.C[which], tc = C / 64;
+    const long base = (long)TIC_BID_Y * gp.in_stride + gp.in_off[which];   // the flat fp32 buffers and w16 share one layout
+    bf16_t* dst = wT + (long)TIC_BID_Y * gp.out_stride + gp.out_off[which];
+    const int r0 = (tile / tc) * 64, c0 = (tile % tc) * 64, t = TIC_TID;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 2 * (i * 16 + (t >> 4)), col = (t & 15) * 4;
+        f32x4 pv[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long o = base + (long)(r0 + row + k) * C + c0 + col;
+            pv[k] = *reinterpret_cast<const f32x4*>(p + o);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + o);
+            f32x4 mv = *reinterpret_cast<const f32x4*>(m + o), vv = *reinterpret_cast<const f32x4*>(v + o);
+            adamw4(pv[k], gv, mv, vv, h);
+            *reinterpret_cast<f32x4*>(p + o) = pv[k];
+            *reinterpret_cast<f32x4*>(m + o) = mv;
+            *reinterpret_cast<f32x4*>(v + o) = vv;
+            *reinterpret_cast<u32x2*>(w16 + o) = u32x2{pack2bf(pv[k][0], pv[k][1]), pack2bf(pv[k][2], pv[k][3])};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_stf((uint32_t)((col + j) * CT_STRIDE + row) * 2u, __builtin_bit_cast(float, pack2bf(pv[0][j], pv[1][j])));
+    }
+    block_sync();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int crow = i * 16 + (t >> 4), rr = (t & 15) * 4;
+        const bf16x4 tv = lds_ld64((uint32_t)(crow * CT_STRIDE + rr) * 2u);
+        *reinterpret_cast<bf16x4*>(dst + (long)(c0 + crow) * R + r0 + rr) = tv;
+    }
+}
+// ... and everything else (biases, LayerNorm, embeddings, head: 0.3 % of ViT-L) by the flat rule, SKIPPING the element ranges the tile kernel owns:
+// inside the layer block [l0, l0 + L * stride) an offset o = (i - l0) % stride lies in a matrix when mat_lo[k] <= o < mat_hi[k]
+struct AdamwSkip {
+    long l0, stride, nlayers;
+    long lo[4], hi[4];
+};
+__global__ void __launch_bounds__(256) adamw_rest_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          bf16_t* __restrict__ w16, long n4, AdamwSkip sk, AdamwHyper h) {
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < n4; i += (long)TIC_NBLK_X * 256) {
+        const long e = i * 4 - sk.l0;   // every range boundary is a multiple of 8 elements (tic_vit_layout pads): a float4 is inside or outside
+        if (e >= 0 && e < sk.nlayers * sk.stride) {
+            const long o = e % sk.stride;
+            bool skip = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) skip = skip || (o >= sk.lo[k] && o < sk.hi[k]);
+            if (skip) continue;
+        }
+        f32x4 pv = *reinterpret_cast<const f32x4*>(p + i * 4);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+        f32x4 mv = *reinterpret_cast<const f32x4*>(m + i * 4), vv = *reinterpret_cast<const f32x4*>(v + i * 4);
+        adamw4(pv, gv, mv, vv, h);
+        *reinterpret_cast<f32x4*>(p + i * 4) = pv;
+        *reinterpret_cast<f32x4*>(m + i * 4) = mv;
+        *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+        *reinterpret_cast<u32x2*>(w16 + i * 4) = u32x2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+    }
+}
+
 // logits[b,c] = bf16( sum_d bf16(z[b,d]) * bf16(W[c,d]) + bf16(bias[c]) ) as fp32; one wave per (b,c)
 __global__ void __launch_bounds__(256) head_fwd_kernel(const bf16_t* __restrict__ z, const float* __restrict__ W, const float* __restrict__ bias,
                                                         float* __restrict__ logits, int B, int C, int D) {

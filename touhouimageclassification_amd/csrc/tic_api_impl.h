@@ -1206,6 +1206,37 @@ extern "C" int tic_vit_refresh_weights(const TicVitState* st, int transposes_onl
     return TIC_OK;
 }
 
+// AdamW over the replica's flat buffers with BOTH bf16 operand copies written in the same pass (torch.optim.AdamW semantics of tic_adamw:
+// TIC/ViT/ntrain.py:39-41, one parameter group, decoupled weight decay on every parameter): the four Linear matrices of every block tile by
+// tile (adamw_tiles_kernel: fp32 update + w16 + wT16), everything else by the flat rule.  After it tic_vit_refresh_weights has nothing to do.
+extern "C" int tic_vit_adamw(const TicVitState* st, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                             tic_stream_t s) {
+    VitCtx c;
+    TIC_TRY(vit_ctx(st, c));
+    TIC_REQUIRE(m && v && step >= 1, "vit_adamw: null moment buffers or step < 1");
+    TIC_REQUIRE(c.D % 64 == 0 && c.F % 64 == 0 && c.L <= 65535, "vit_adamw: needs hidden / MLP widths that are multiples of 64 (use tic_adamw + tic_vit_refresh_weights)");
+    const TicVitLayout& y = c.lay;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamwHyper h;
+    h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.wd = weight_decay; h.inv_bc1 = (float)(1.0 / bc1); h.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    CastTransposeGroup gp;
+    AdamwSkip sk;
+    const long in_off[4] = {y.wqkv, y.wo, y.w1, y.w2}, out_off[4] = {y.t_wqkv, y.t_wo, y.t_w1, y.t_w2};
+    const long R[4] = {3 * c.D, c.D, c.F, c.D}, C[4] = {c.D, c.D, c.D, c.F};
+    int tiles = 0;
+    for (int i = 0; i < 4; ++i) {
+        gp.in_off[i] = y.layer0 + in_off[i]; gp.out_off[i] = out_off[i]; gp.R[i] = (int)R[i]; gp.C[i] = (int)C[i];
+        tiles += (int)((R[i] / 64) * (C[i] / 64));
+        gp.tile_end[i] = tiles;
+        sk.lo[i] = in_off[i]; sk.hi[i] = in_off[i] + R[i] * C[i];
+    }
+    gp.in_stride = y.layer_stride; gp.out_stride = y.t_layer_stride;
+    sk.l0 = y.layer0; sk.stride = y.layer_stride; sk.nlayers = c.L;
+    TIC_LAUNCH(adamw_tiles_kernel, dim3(tiles, (unsigned)c.L), 256, 64 * CT_STRIDE * 2, s, c.P, c.G, m, v, c.W16, c.WT, gp, h);
+    TIC_LAUNCH(adamw_rest_kernel, ew_grid(y.n_params / 4), 256, 0, s, c.P, c.G, m, v, c.W16, y.n_params / 4, sk, h);
+    return tic_after_launch("vit_adamw");
+}
+
 static int vit_forward_impl(const TicVitState* st, const float* x, float* logits_out, bool infer, tic_stream_t s);
 extern "C" int tic_vit_forward(const TicVitState* st, const float* x, float* logits_out, tic_stream_t s) {
     return vit_forward_impl(st, x, logits_out, false, s);

@@ -179,6 +179,11 @@ class VitEngine:
         self._weights_version = -1
         self._w16_fresh = w16_fresh
 
+    def mark_weights_clean(self) -> None:
+        """the fused AdamW (tic_vit_adamw) wrote w16 AND the transposes: nothing to refresh until the fp32 weights change again"""
+        self._weights_version = self._version()
+        self._w16_fresh = False
+
     def refresh_weights_if_needed(self) -> None:
         """bf16 operand copies follow the fp32 master weights (torch bumps `_version` on every in-place
         update of any view, e.g. optimizer.step(); our own AdamW keeps w16 fresh and calls mark_*)."""

@@ -23,6 +23,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step = 0
         self._m = self._v = None
+        self.one_pass = True   # tic_vit_adamw (update + both bf16 operand copies in one pass) where it applies; False: tic_adamw + refresh (A/B)
         # frozen encoder (ntrain.py:35-37, full_finetune=False): only the head range is stepped
         e = model._engine
         all_trainable = all(p.requires_grad for p in model.parameters())
@@ -45,6 +46,15 @@ class FusedAdamW(torch.optim.Optimizer):
             self._v = torch.zeros_like(e.params)
         self._step += 1
         a, b = self._range
+        if self.one_pass and (a, b) == (0, e.lay.n_params) and e.D % 64 == 0 and e.F % 64 == 0 and e.w16 is not None:
+            # full fine-tuning: one pass updates the fp32 state AND writes both bf16 operand copies (w16 and the transposes the dX GEMMs
+            # read) -- no cast + transpose pass over the weights before the next forward
+            import ctypes
+            _, st, _ = e._state(e._cur_B or 1)
+            e.backend.call("tic_vit_adamw", ctypes.byref(st), self._m.data_ptr(), self._v.data_ptr(), float(g["lr"]), float(g["betas"][0]),
+                           float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step, e.backend.stream())
+            e.mark_weights_clean()
+            return loss
         a -= a % 4
         n = b - a
         w16 = e.w16
