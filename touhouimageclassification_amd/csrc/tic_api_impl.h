@@ -97,6 +97,7 @@ static int g_opt_tn_mfma = 0;     // MFMA shape of the grouped dW stream-K launc
                                   // but +2..5 % at M = 12 608, tools/dw_ab.py tn_mfma 16 32), 16, 32
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 #if defined(TIC_SIM) || defined(TIC_MEASURE)
+static int g_opt_tn_waves = 8;   // experiment: 4 = the one-wave-per-SIMD form of the grouped dW tile (gemm_tn256.h tn256_tile_segment16_w4)
 static int g_opt_nt_fault = 0;   // test builds: part 0 of every split tile withholds its flag (exercises the timeout report of flag_wait)
 #endif
 // The SIX knobs of the product library select between numerically equivalent routes, so that the parity tests can force each one
@@ -128,6 +129,10 @@ extern "C" int tic_set_option(const char* name, int value) {
         return TIC_OK;
     }
 #if defined(TIC_SIM) || defined(TIC_MEASURE)
+    if (name && !strcmp(name, "tn_waves") && (value == 4 || value == 8)) {
+        g_opt_tn_waves = value;
+        return TIC_OK;
+    }
     if (name && !strcmp(name, "nt_fault") && (value == 0 || value == 1)) {
         g_opt_nt_fault = value;
         return TIC_OK;
@@ -500,6 +505,12 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
                 return tic_after_launch("gemm_tn(stream-K)");
             }
             TIC_RT_TIMER_MARK(0, stream);
+#if defined(TIC_MEASURE) || defined(TIC_SIM)
+            if (g_opt_tn_waves == 4) {
+                TIC_RT_MAX_LDS(gemm_tn256_streamk_w4_kernel, G256_LDS_BYTES);
+                TIC_LAUNCH(gemm_tn256_streamk_w4_kernel, grid_wg, 256, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
+            } else
+#endif
             if (g_opt_tn_mfma == 32 || (g_opt_tn_mfma == 0 && nsteps < 512)) {
                 TIC_RT_MAX_LDS(gemm_tn256_streamk_mfma32_kernel, G256_LDS_BYTES);
                 TIC_LAUNCH(gemm_tn256_streamk_mfma32_kernel, grid_wg, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
