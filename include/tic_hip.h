@@ -101,6 +101,10 @@ int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K
  * full-reduction 256x256 tiles (no split-K, no atomics) when shapes allow, else one launch per problem */
 int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N,
                            const int* K, int M, tic_stream_t stream);
+/* overwrite != 0: C_g = A_g^T . B_g -- what C held is dropped and need not be initialised (the first backward after the gradients were
+ * cleared: no read of C, no zeroing pass).  Routes that add partial tiles (stream-K shares, row parts) zero C themselves first. */
+int tic_gemm_tn_group_bf16_ex(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N,
+                              const int* K, int M, int overwrite, tic_stream_t stream);
 
 /* LayerNorm(eps) over the last dim of fp32 rows -> bf16; saves mean / rstd.  in_stride = elements
  * between consecutive input rows (D for the token stream, N*D to pick the CLS rows).  HF:261-262,274,281,385. */
@@ -322,6 +326,12 @@ int tic_vit_forward_infer(const TicVitState* st, const float* pixel_values, floa
  *   head (classifier + final LN), layer l = L-1 .. 0, embeddings.  grads are ACCUMULATED into st->grads. */
 int tic_vit_backward_head(const TicVitState* st, const float* dlogits, tic_stream_t stream);
 int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stream_t stream);
+/* overwrite_dw != 0: the four weight-matrix gradients of the block are STORED (their ranges of st->grads need not be zero); biases and
+ * LayerNorm gradients still accumulate.  Pairs with tic_vit_zero_grads(st, 1, ...). */
+int tic_vit_backward_layer_ex(const TicVitState* st, int layer, int overwrite_dw, tic_stream_t stream);
+/* st->grads = 0 before a backward (optimizer.zero_grad()).  keep_matrices != 0 leaves the per-layer weight-matrix ranges (99.7 % of
+ * ViT-L) untouched, for a backward that stores them: tic_vit_backward_layer_ex(..., 1, ...) */
+int tic_vit_zero_grads(const TicVitState* st, int keep_matrices, tic_stream_t stream);
 int tic_vit_backward_embed(const TicVitState* st, tic_stream_t stream);
 
 /* ---- mixture of ViT experts: gate / combine / loss arithmetic (BASELINE config 5) ------------------------------------

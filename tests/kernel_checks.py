@@ -248,6 +248,12 @@ def check_gemm_tn_group(env, M, shapes):
     call("tic_gemm_tn_group_bf16", n, PA, PB, PC, NN, KK, M, None)
     for c, r in zip(Cs, refs):
         torch.testing.assert_close(c, r, atol=2e-3 * max(1.0, (M / 200) ** 0.5), rtol=1e-3)
+    # overwrite form (the first backward after the gradients were cleared): whatever C held -- NaNs here -- is dropped, on every route
+    for c in Cs:
+        c.fill_(float("nan"))
+    call("tic_gemm_tn_group_bf16_ex", n, PA, PB, PC, NN, KK, M, 1, None)
+    for a, b, c in zip(As, Bs, Cs):
+        torch.testing.assert_close(c, a.float().t() @ b.float(), atol=2e-3 * max(1.0, (M / 200) ** 0.5), rtol=1e-3)
 
 
 def aug_cases(H, W):
@@ -501,6 +507,59 @@ def check_splitk_nt(env, M, N, K, split, tile=128):
         env._call("tic_gemm_nt_scratch", None, 0)
         env._call("tic_set_option", b"gemm_tile", 0)
         env._call("tic_set_option", b"gemm_split", -1)
+
+
+def check_nt_ring_matches(env, M, N, K, split=0):
+    """the 4-stage ring of the 128x128 NT kernel (gemm.h NST = 4: at most 256 workgroups, each alone on its CU) forms the same products in
+    the same order as the 2-stage loop: every epilogue's outputs agree BIT FOR BIT.  Test / measurement builds switch the form with the
+    `nt_deep` knob (also under the split-K hand-off); the product library has no such knob -- there the SAME rows are computed once as an
+    M-row product (<= 256 tiles: ring) and once as the first M rows of a taller product (> 256 tiles: 2-stage loop)."""
+    from touhouimageclassification_amd import _capi
+    rnd, call, dev = env.rnd, env.call, env.dev
+    tiles_n = (N + 127) // 128
+    try:
+        env._call("tic_set_option", b"nt_deep", -1)
+        knob = True
+    except _capi.TicError:
+        knob = False
+        assert split == 0, "product library: the split-K ring is covered by check_splitk_nt (auto route) against fp32 math"
+    assert ((M + 127) // 128) * tiles_n * max(1, split) <= 256
+    Mb = M if knob else 128 * (256 // tiles_n + 1)   # taller product: more than 256 tiles
+    A, B, bias = bf(rnd(Mb, K, scale=0.3)), bf(rnd(N, K, scale=0.3)), rnd(N, scale=0.1)
+    resid, aux = rnd(Mb, N), bf(rnd(Mb, N))
+    scratch = torch.zeros(_capi.NT_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+
+    def run(epi, rows, deep):
+        if knob:
+            env._call("tic_set_option", b"nt_deep", deep)
+        o1 = torch.full((rows, N), 3.0, device=dev).to(torch.bfloat16)
+        o2 = torch.full((rows, N), 5.0, device=dev).to(torch.bfloat16)
+        of = torch.full((rows, N), 7.0, device=dev)
+        cs = torch.zeros(N, device=dev)
+        has_cs = epi in (0, 3, 6)
+        call("tic_gemm_nt_bf16_ex", ptr(A), ptr(B), rows, N, K, epi, ptr(bias) if epi in (0, 1, 2, 5) else None, ptr(o1), ptr(o2), ptr(of),
+             ptr(resid) if epi == 2 else None, ptr(aux) if epi in (3, 6, 7) else None, None, 0, ptr(cs) if has_cs else None, None)
+        return o1[:M], o2[:M], of[:M], cs
+
+    env._call("tic_set_option", b"gemm_tile", 128)
+    env._call("tic_set_option", b"gemm_split", split)
+    if split:
+        env._call("tic_gemm_nt_scratch", ptr(scratch), scratch.numel())
+    try:
+        for epi in (0, 1, 2, 3, 5, 6, 7):
+            a, b = run(epi, Mb, 0), run(epi, M, 1)
+            for x, y in zip(a[:3], b[:3]):
+                assert torch.equal(x, y), (epi, M, N, K, split)
+            if knob:   # the column sums are fp32 atomics of per-wave sums: same addends, the order of the adds is the hardware's
+                torch.testing.assert_close(a[3], b[3], atol=1e-3 * max(1.0, float(a[3].abs().max())), rtol=1e-5)
+        ref = A[:M].float() @ B.float().t() + bias
+        torch.testing.assert_close(run(0, M, 1)[0].float(), ref, atol=0.06, rtol=0.02)
+    finally:
+        env._call("tic_gemm_nt_scratch", None, 0)
+        env._call("tic_set_option", b"gemm_tile", 0)
+        env._call("tic_set_option", b"gemm_split", -1)
+        if knob:
+            env._call("tic_set_option", b"nt_deep", -1)
 
 
 def check_refresh_weights(model):

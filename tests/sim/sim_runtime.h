@@ -352,6 +352,7 @@ TIC_DEV float wave64_sum(float v) {
 }
 TIC_DEV uint32_t lds_base() { return 0u; }
 TIC_DEV bf16x4 lds_tr64_hidden(uint32_t addr, uint32_t imm) { return lds_tr64(addr + imm); }
+TIC_DEV bf16x8 lds_ld128_hidden(uint32_t addr, uint32_t imm) { return lds_ld128(addr + imm); }
 template <int N = 0> TIC_DEV void lds_wait(bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}
 template <int N = 0> TIC_DEV void lds_wait(bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&, bf16x8&) {}
 TIC_DEV float fast_log2(float x) { return log2f(x); }

@@ -57,5 +57,7 @@ def test_register_budgets(kernels):
             if n.startswith(prefix):
                 # (the split-K forms <EPI, false, 1> batch the 16 slab loads of the hand-off: LDS allows two workgroups per CU = 2 waves
                 # per SIMD anyway, so they may use the 256-register half)
-                limit = 256 if n.rstrip().endswith(", false, 1>(GemmNtParams)") else 128
+                # the 4-stage ring forms <EPI, false, SPLITK, 4> use 128 KiB of LDS: one workgroup = one wave per SIMD, any register count
+                # up to 256 costs nothing; they hold two k-halves of fragments (64 registers) beside the 64 accumulators
+                limit = 256 if n.rstrip().endswith((", false, 1, 2>(GemmNtParams)", ", 4>(GemmNtParams)")) else 128
                 assert k["vgpr_count"] <= limit, (prefix, n, k)

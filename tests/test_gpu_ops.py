@@ -129,3 +129,11 @@ def test_gemm_tn_parts_slab_route(env, M, N, K):
 def test_splitk_nt_kernel_128(env, M, N, K, split):
     """the 128x128 kernel's split-K form at ViT-L's 8 / 16-image shapes (104 / 200 tiles)"""
     kc.check_splitk_nt(env, M, N, K, split, tile=128)
+
+
+@pytest.mark.parametrize("M,N,K", [(1576, 1024, 4096), (3152, 1024, 3072), (1576, 1024, 1024), (130, 128, 64), (300, 256, 192)])
+def test_nt_ring_of_four_stages_matches_two_stage_loop(env, M, N, K):
+    """the 4-stage ring of the 128x128 NT kernel (what ViT-L's N = 1024 products run on at 8-16 images per GPU) against the 2-stage loop:
+    bit-identical for every epilogue; 1 and 3 K tiles leave the ring partly empty.  (Its split-K form at these shapes:
+    test_splitk_nt_kernel_128, whose 104 x 2 workgroups take the ring by the same rule; bit-equality under the hand-off: simulator.)"""
+    kc.check_nt_ring_matches(env, M, N, K, 0)

@@ -145,3 +145,9 @@ def test_splitk_nt_kernel_128(env, M, N, K, split):
 
 def test_splitk_timeout_is_reported(env):
     kc.check_splitk_timeout_is_reported(env)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(200, 256, 64, 0), (130, 128, 128, 0), (70, 128, 192, 0), (200, 256, 512, 0), (200, 128, 512, 2), (130, 128, 1024, 4)])
+def test_nt_ring_of_four_stages_matches_two_stage_loop(env, M, N, K, split):
+    """1, 2, 3 K tiles (ring not full), 8 K tiles, and the split-K hand-off on top of it: bit-identical outputs for every epilogue"""
+    kc.check_nt_ring_matches(env, M, N, K, split)

@@ -202,3 +202,30 @@ def test_fused_adamw_writes_both_operand_copies_and_equals_the_flat_rule():
     with torch.no_grad():
         m(x)
     assert "tic_vit_refresh_weights" not in refreshed and "tic_vit_forward_infer" in refreshed
+
+
+def test_fused_step_stores_matrix_gradients_over_stale_values_and_zeroes_the_rest():
+    """`fused_train_step` clears only the gradient ranges that accumulate (`tic_vit_zero_grads(st, 1)`: biases, LayerNorm, embeddings, head)
+    and its backward STORES the weight-matrix gradients (`tic_vit_backward_layer_ex(..., 1)`): with the whole buffer poisoned beforehand,
+    every gradient equals, bit for bit, the one the autograd path accumulates into a zeroed buffer."""
+    from touhouimageclassification_amd.optim import FusedAdamW
+    from touhouimageclassification_amd.step import fused_train_step
+    torch.manual_seed(5)
+    m = ViT(10, pretrained=False, model_name="tiny", backend=SimBackend())
+    e = m._engine
+    x, y = torch.randn(2, 3, 224, 224), torch.tensor([1, 8])
+    m.zero_grad()
+    torch.nn.functional.cross_entropy(m(x).logits, y).backward()
+    want = e.grads.clone()
+    assert float(want.abs().max()) > 0
+    opt = FusedAdamW(m, lr=0.0, weight_decay=0.0)    # lr 0: the parameters stay, only the gradients are compared
+    e.grads.fill_(float("nan"))
+    fused_train_step(m, opt, x, y)
+    assert torch.equal(e.grads, want)
+    assert not e._dw_overwrite
+    # a head-only backward after the partial clear would leave the matrix ranges undefined: refused
+    e.zero_grads(2, keep_matrices=True)
+    with pytest.raises(RuntimeError, match="FULL backward"):
+        e.backward(torch.zeros(2, 10), head_only=True)
+    e.zero_grads(2)
+    assert float(e.grads.abs().max()) == 0 and not e._dw_overwrite

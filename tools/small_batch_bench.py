@@ -34,6 +34,11 @@ def main():
     D, F = 1024, 4096
     scratch = torch.zeros(_capi.NT_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
     call("tic_gemm_nt_scratch", scratch.data_ptr(), scratch.numel())
+    try:
+        call("tic_set_option", b"nt_deep", -1)
+        HAVE_RING_KNOB = True
+    except Exception:
+        HAVE_RING_KNOB = False
     for B in args.batch:
         M = B * 197
         shapes = [("qkv", 3 * D, D, 0), ("o_proj+res", D, D, 2), ("fc1+gelu", F, D, 1), ("fc2+res", D, F, 2),
@@ -53,9 +58,16 @@ def main():
                 call("tic_gemm_nt_bf16", a.data_ptr(), w.data_ptr(), M, n, k, epi, None if epi == 3 else bias.data_ptr(), o1.data_ptr(), o2.data_ptr(),
                      None if of is None else of.data_ptr(), None if resid is None else resid.data_ptr(), None if aux is None else aux.data_ptr(), None, 0, current_stream())
             row = []
-            for label, tile, sp in (("128", 128, 0), ("128/2", 128, 2), ("128/4", 128, 4), ("256", 256, 0), ("auto", 0, -1)):
+            # ring = the 4-stage form of the 128x128 kernel (gemm.h NST = 4); forcing it on / off needs the measurement library
+            # (TIC_HIP_LIB=.../libtic_hip_dbg.so); the product library chooses by itself ("auto")
+            cfgs = (("128", 128, 0, 0), ("128r", 128, 0, 1), ("128/2", 128, 2, 0), ("128r/2", 128, 2, 1), ("128r/4", 128, 4, 1), ("256", 256, 0, -1), ("auto", 0, -1, -1))
+            for label, tile, sp, ring in cfgs:
                 call("tic_set_option", b"gemm_tile", tile)
                 call("tic_set_option", b"gemm_split", sp)
+                if HAVE_RING_KNOB:
+                    call("tic_set_option", b"nt_deep", ring)
+                elif ring == 1:
+                    continue
                 us = time_us(run)
                 row.append(f"{label} {us:6.1f}")
                 tot[label] = tot.get(label, 0.0) + us
@@ -64,6 +76,8 @@ def main():
         print(f"B={B:3d} sum over the 8 NT launches of a block: " + "  ".join(f"{k} {v:6.1f}" for k, v in tot.items()), flush=True)
         call("tic_set_option", b"gemm_tile", 0)
         call("tic_set_option", b"gemm_split", -1)
+        if HAVE_RING_KNOB:
+            call("tic_set_option", b"nt_deep", -1)
         # dW: per problem (128x128 split-M) vs the grouped stream-K launch
         ns, ks = [3 * D, D, F, D], [D, D, D, F]
         As = [torch.randn(M, n, device=dev).to(torch.bfloat16) for n in ns]

@@ -57,6 +57,7 @@ SIGNATURES = {
     "tic_attention_bwd_ws": ([P, P, P, P, P, P, P, I, I, I, I, F, P], I),
     "tic_gemm_tn_bf16": ([P, P, P, I, I, I, P], I),
     "tic_gemm_tn_group_bf16": ([I, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I), I, P], I),
+    "tic_gemm_tn_group_bf16_ex": ([I, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(I), C.POINTER(I), I, I, P], I),
     "tic_layernorm_fwd": ([P, L, P, P, P, P, P, I, I, F, P], I),
     "tic_layernorm_bwd": ([P, P, L, P, P, P, P, P, P, P, P, I, I, P], I),
     "tic_attention_fwd": ([P, P, P, I, I, I, F, P], I),
@@ -110,6 +111,8 @@ SIGNATURES = {
     "tic_vit_forward_infer": ([C.POINTER(TicVitState), P, P, P], I),
     "tic_vit_backward_head": ([C.POINTER(TicVitState), P, P], I),
     "tic_vit_backward_layer": ([C.POINTER(TicVitState), I, P], I),
+    "tic_vit_backward_layer_ex": ([C.POINTER(TicVitState), I, I, P], I),
+    "tic_vit_zero_grads": ([C.POINTER(TicVitState), I, P], I),
     "tic_vit_backward_embed": ([C.POINTER(TicVitState), P], I),
 }
 

@@ -222,32 +222,52 @@ __global__ void __launch_bounds__(256) adamw_tiles_kernel(float* __restrict__ p,
         *reinterpret_cast<bf16x4*>(dst + (long)(c0 + crow) * R + r0 + rr) = tv;
     }
 }
-// ... and everything else (biases, LayerNorm, embeddings, head: 0.3 % of ViT-L) by the flat rule, SKIPPING the element ranges the tile kernel owns:
-// inside the layer block [l0, l0 + L * stride) an offset o = (i - l0) % stride lies in a matrix when mat_lo[k] <= o < mat_hi[k]
-struct AdamwSkip {
-    long l0, stride, nlayers;
-    long lo[4], hi[4];
+// The element ranges OUTSIDE the per-layer weight matrices (biases, LayerNorm, embeddings, head: 0.3 % of ViT-L), as a launch grid:
+// grid (L + 2, 5): block (l, k) walks gap k of layer l (the <= 5 stretches between / around its four matrices); x = L walks [0, l0),
+// x = L + 1 walks [l0 + L * stride, n) (there y strides).  Every boundary is a multiple of 8 elements (tic_vit_layout pads).
+// (The first version tested every float4 of the whole buffer against the ranges with a 64-bit modulo: 82 us for 0.3 % of the bytes.)
+struct RestGaps {
+    long l0, stride, nlayers, n;
+    long lo[5], len[5];   // relative to the layer's start
 };
-__global__ void __launch_bounds__(256) adamw_rest_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                          bf16_t* __restrict__ w16, long n4, AdamwSkip sk, AdamwHyper h) {
-    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < n4; i += (long)TIC_NBLK_X * 256) {
-        const long e = i * 4 - sk.l0;   // every range boundary is a multiple of 8 elements (tic_vit_layout pads): a float4 is inside or outside
-        if (e >= 0 && e < sk.nlayers * sk.stride) {
-            const long o = e % sk.stride;
-            bool skip = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) skip = skip || (o >= sk.lo[k] && o < sk.hi[k]);
-            if (skip) continue;
-        }
-        f32x4 pv = *reinterpret_cast<const f32x4*>(p + i * 4);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
-        f32x4 mv = *reinterpret_cast<const f32x4*>(m + i * 4), vv = *reinterpret_cast<const f32x4*>(v + i * 4);
-        adamw4(pv, gv, mv, vv, h);
-        *reinterpret_cast<f32x4*>(p + i * 4) = pv;
-        *reinterpret_cast<f32x4*>(m + i * 4) = mv;
-        *reinterpret_cast<f32x4*>(v + i * 4) = vv;
-        *reinterpret_cast<u32x2*>(w16 + i * 4) = u32x2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+TIC_DEV void rest_range(const RestGaps& z, long& start, long& n4, long& first, long& step) {
+    const long x = TIC_BID_X;
+    first = TIC_TID;
+    step = 256;
+    if (x < z.nlayers) {
+        start = z.l0 + x * z.stride + z.lo[TIC_BID_Y];
+        n4 = z.len[TIC_BID_Y] / 4;
+    } else {
+        start = (x == z.nlayers) ? 0 : z.l0 + z.nlayers * z.stride;
+        n4 = ((x == z.nlayers) ? z.l0 : z.n - start) / 4;
+        first += (long)TIC_BID_Y * 256;
+        step *= TIC_NBLK_Y;
     }
+}
+// ... and everything else by the flat rule
+__global__ void __launch_bounds__(256) adamw_rest_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          bf16_t* __restrict__ w16, RestGaps z, AdamwHyper h) {
+    long start, n4, first, step;
+    rest_range(z, start, n4, first, step);
+    for (long j = first; j < n4; j += step) {
+        const long i = start + j * 4;
+        f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+        f32x4 mv = *reinterpret_cast<const f32x4*>(m + i), vv = *reinterpret_cast<const f32x4*>(v + i);
+        adamw4(pv, gv, mv, vv, h);
+        *reinterpret_cast<f32x4*>(p + i) = pv;
+        *reinterpret_cast<f32x4*>(m + i) = mv;
+        *reinterpret_cast<f32x4*>(v + i) = vv;
+        *reinterpret_cast<u32x2*>(w16 + i) = u32x2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+    }
+}
+
+// g = 0 outside the weight-matrix ranges: the gradients that ACCUMULATE (bias / LayerNorm column sums, embeddings, head) start from
+// zero while the matrix gradients, which the backward stores whole, are not touched
+__global__ void __launch_bounds__(256) zero_gaps_kernel(float* __restrict__ g, RestGaps z) {
+    long start, n4, first, step;
+    rest_range(z, start, n4, first, step);
+    for (long j = first; j < n4; j += step) *reinterpret_cast<f32x4*>(g + start + j * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // logits[b,c] = bf16( sum_d bf16(z[b,d]) * bf16(W[c,d]) + bf16(bias[c]) ) as fp32; one wave per (b,c)

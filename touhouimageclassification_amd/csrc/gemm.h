@@ -193,6 +193,17 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
     }
 }
 
+// a bare s_barrier (no s_waitcnt vmcnt(0) in front of it, unlike __syncthreads): LDS-DMA stays in flight across it
+TIC_DEV void raw_sync() {
+#ifndef TIC_SIM
+    asm volatile("" ::: "memory");
+#endif
+    raw_barrier();
+#ifndef TIC_SIM
+    asm volatile("" ::: "memory");
+#endif
+}
+
 #define GEMM_BM 128
 #define GEMM_BN 128
 #define GEMM_BK 64
@@ -204,8 +215,14 @@ TIC_DEV void gemm_epilogue(const GemmNtParams& p, RowF row_of, ColF col_of, AccF
 // Parts before the last store their fp32 accumulators (64 KiB, coalesced float4 per lane) to p.slab and publish p.flags[tile * 4 + part]
 // = p.epoch; the last part (highest block ids: its producers are always dispatched first) waits, adds the slabs in part order and
 // runs the ordinary epilogue.  Same hand-off as gemm256.h's split-K form.
-template <int EPI, bool CONV = false, int SPLITK = 0>
+// NST = 4 (few workgroups: every one alone on its CU, so the second workgroup that would hide a 2-stage loop's load latency is not
+// there -- ViT-L at 8-16 images per GPU, N = 1024: 104-208 workgroups whose 16-64 K steps each waited ~1 us for ONE 32 KiB stage):
+// a ring of four stages (128 KiB), three in flight (96 KiB per CU > the ~60 KB that cover the CU's LDS-DMA intake x latency), counted
+// vmcnt, one raw barrier per step, fragment reads hidden from hipcc (it would drain the ring in front of every one).  Same products in
+// the same order as NST = 2: the two forms agree bit for bit.
+template <int EPI, bool CONV = false, int SPLITK = 0, int NST = 2>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
+    static_assert(NST == 2 || NST == 4, "gemm_nt_kernel: 2 or 4 stages");
     const int tid = TIC_TID, l = tid & 63, w = wave_id();
     const int wm = w >> 1, wn = w & 1;
     const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;   // B rows >= N read 0
@@ -302,6 +319,45 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
     }
 
     const int nk = (p.K / GEMM_BK) / nparts, kt0 = part * nk;   // K tiles of THIS workgroup
+    if constexpr (NST == 4) {
+        const uint32_t la[2] = {lds_base() + a_base + fo[0], lds_base() + a_base + fo[1]};
+        const uint32_t lb[2] = {lds_base() + b_base + fo[0], lds_base() + b_base + fo[1]};
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (s < nk) stage(s, kt0 + s);
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt has landed once at most min(2, nk - 1 - kt) younger stages (8 loads per lane each) are outstanding
+            const int younger = nk - 1 - kt;
+            if (younger >= 2) wait_vmcnt<16>();
+            else if (younger == 1) wait_vmcnt<8>();
+            else wait_vmcnt0();
+            raw_sync();   // every wave's pieces of stage kt are in LDS, and every wave has finished reading stage kt - 1 ...
+            if (kt + 3 < nk) stage((kt + 3) & 3, kt0 + kt + 3);   // ... whose buffer this refills
+            const uint32_t sb = (uint32_t)(kt & 3) * GEMM_STAGE_BYTES;
+            bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[0][t] = lds_ld128_hidden(la[0] + sb, (uint32_t)t * 2048u);
+                fb[0][t] = lds_ld128_hidden(lb[0] + sb, (uint32_t)t * 2048u);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[1][t] = lds_ld128_hidden(la[1] + sb, (uint32_t)t * 2048u);
+                fb[1][t] = lds_ld128_hidden(lb[1] + sb, (uint32_t)t * 2048u);
+            }
+            lds_wait<8>(fa[0][0], fa[0][1], fa[0][2], fa[0][3], fb[0][0], fb[0][1], fb[0][2], fb[0][3]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb[0][nt], fa[0][mt], acc[mt][nt]);
+            sched_fence();   // else hipcc hoists the second wait above these 16 MFMAs and the k-half-1 reads are not overlapped
+            lds_wait<0>(fa[1][0], fa[1][1], fa[1][2], fa[1][3], fb[1][0], fb[1][1], fb[1][2], fb[1][3]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb[1][nt], fa[1][mt], acc[mt][nt]);
+        }
+    } else {
     stage(0, kt0);
     wait_vmcnt0();
     block_sync();
@@ -325,6 +381,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmNtParams p) {
         }
         wait_vmcnt0();
         block_sync();
+    }
     }
 
     if (SPLITK) {   // thread t owns float4 slots t, 256 + t, ... of a 64-KiB slab

@@ -767,6 +767,22 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(GemmTnGroupParams gp
     tn256_tile_segment<0, DBG>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, (gp.M + 63) / 64);
 }
 
+// The same launch STORING its tiles (C = dY^T X): the caller states that C holds nothing to keep -- the first backward after the
+// gradients were dropped.  Saves the read of C (256 KiB per workgroup at one CU's ~25 GB/s = 10 us per launch) and the zeroing of it.
+__global__ void __launch_bounds__(512, 2) gemm_tn256_store_kernel(GemmTnGroupParams gp) {
+    int wg;
+    {
+        const int bid = TIC_BID_X, nwg = gp.total_tiles;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const bf16_t *Ap, *Bp;
+    float* Cp;
+    int N, K, n0, k0;
+    tn_tile_lookup(gp, wg, Ap, Bp, Cp, N, K, n0, k0);
+    tn256_tile_segment<2>(Ap, Bp, Cp, N, K, gp.M, n0, k0, 0, (gp.M + 63) / 64);
+}
+
 // Stream-K forms: every CU gets an equal share of the (tile, M step) work instead of 192 busy + 64 idle CUs.  A share is
 // processed as the segments it has inside single tiles, each through the pipelined tile routine, and every partial
 // tile is ADDED to C with fp32 atomics.

@@ -98,6 +98,7 @@ static int g_opt_tn_mfma = 0;     // MFMA shape of the grouped dW stream-K launc
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 #if defined(TIC_SIM) || defined(TIC_MEASURE)
 static int g_opt_tn_waves = 8;   // experiment: 4 = the one-wave-per-SIMD form of the grouped dW tile (gemm_tn256.h tn256_tile_segment16_w4)
+static int g_opt_nt_deep = -1;    // test / measurement builds: 4-stage form of the 128x128 NT kernel: -1 auto (<= 256 workgroups), 0 never, 1 always
 static int g_opt_nt_fault = 0;   // test builds: part 0 of every split tile withholds its flag (exercises the timeout report of flag_wait)
 #endif
 // The SIX knobs of the product library select between numerically equivalent routes, so that the parity tests can force each one
@@ -131,6 +132,10 @@ extern "C" int tic_set_option(const char* name, int value) {
 #if defined(TIC_SIM) || defined(TIC_MEASURE)
     if (name && !strcmp(name, "tn_waves") && (value == 4 || value == 8)) {
         g_opt_tn_waves = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "nt_deep") && value >= -1 && value <= 1) {
+        g_opt_nt_deep = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "nt_fault") && (value == 0 || value == 1)) {
@@ -273,8 +278,10 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         for (int sp = 4; sp >= 2; sp >>= 1) {
             if (g_opt_gemm_split > 0 && sp != g_opt_gemm_split) continue;
             if (nk_ % sp != 0 || (long)grid * sp > 512 || grid > 256 || (size_t)grid * (sp - 1) * 65536 > TIC_NT_SLAB_BYTES) continue;
-            // auto: two parts only (four measured slower at every shape: 38.0 vs 34.0, 42.7 vs 33.8 us), each >= 16 K tiles
-            if (g_opt_gemm_split < 0 && (sp != 2 || nk_ / sp < 16)) continue;
+            // auto: two parts only (four measured slower at every shape: 38.0 vs 34.0, 42.7 vs 33.8 us), each >= 16 K tiles, and only while
+            // both parts of every tile still get a CU of their own (<= 256 workgroups: the 4-stage ring below; 200 tiles at 16 images:
+            // unsplit ring 41.7 / 38.9 / 30.9 us against 46.7 / 43.7 / 38.1 split on the 2-stage loop, profiles/r03_small_batch_ring.log)
+            if (g_opt_gemm_split < 0 && (sp != 2 || nk_ / sp < 16 || (long)grid * sp > 256)) continue;
             split = sp;
             break;
         }
@@ -289,8 +296,12 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
     if (split > 1 && p.epoch == 0) p.epoch = ++g_nt_epoch;   // 0 is what freshly zeroed flags hold
     p.err = g_err_dev;
     p.fault = 0;
+    // at most one workgroup per CU anyway: the 4-stage ring (128 KiB of LDS) covers the load latency that a second resident workgroup
+    // would otherwise hide (gemm.h NST)
+    bool deep = !big && (long)grid * split <= 256;
 #if defined(TIC_SIM) || defined(TIC_MEASURE)
     p.fault = g_opt_nt_fault;
+    if (g_opt_nt_deep >= 0) deep = !big && g_opt_nt_deep == 1;
 #endif
 #ifdef TIC_MEASURE
 #define TIC_GEMM_NT_LAUNCH_B(E)                                                                      \
@@ -310,9 +321,15 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
         if (big) {                                                                                   \
             TIC_RT_MAX_LDS(gemm_nt256_kernel<E>, G256_NT_LDS_BYTES);                                 \
             TIC_LAUNCH(gemm_nt256_kernel<E>, grid, 512, G256_NT_LDS_BYTES, stream, p);               \
+        } else if (split > 1 && deep) {                                                              \
+            TIC_RT_MAX_LDS((gemm_nt_kernel<E, false, 1, 4>), 4 * GEMM_STAGE_BYTES);                  \
+            TIC_LAUNCH((gemm_nt_kernel<E, false, 1, 4>), grid * split, 256, 4 * GEMM_STAGE_BYTES, stream, p); \
         } else if (split > 1) {                                                                      \
             TIC_RT_MAX_LDS((gemm_nt_kernel<E, false, 1>), GEMM_LDS_BYTES);                           \
             TIC_LAUNCH((gemm_nt_kernel<E, false, 1>), grid * split, 256, GEMM_LDS_BYTES, stream, p); \
+        } else if (deep) {                                                                           \
+            TIC_RT_MAX_LDS((gemm_nt_kernel<E, false, 0, 4>), 4 * GEMM_STAGE_BYTES);                  \
+            TIC_LAUNCH((gemm_nt_kernel<E, false, 0, 4>), grid, 256, 4 * GEMM_STAGE_BYTES, stream, p); \
         } else {                                                                                     \
             TIC_RT_MAX_LDS(gemm_nt_kernel<E>, GEMM_LDS_BYTES);                                       \
             TIC_LAUNCH(gemm_nt_kernel<E>, grid, 256, GEMM_LDS_BYTES, stream, p);                     \
@@ -379,7 +396,7 @@ extern "C" int tic_gemm_nt_bf16_ex(const void* A, const void* B, int M, int N, i
 }
 
 static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N, const int* K, int M,
-                              bool force256, tic_stream_t stream);
+                              bool force256, bool overwrite, tic_stream_t stream);
 extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, tic_stream_t stream) {
     TIC_REQUIRE(A && B && C, "gemm_tn: null operand");
     // long reductions over 256-aligned outputs (the 1x1-convolution weight gradients of ResNet: a handful of tiles, M up to 10^5
@@ -390,7 +407,7 @@ extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, i
         const void* b1[1] = {B};
         float* c1[1] = {C};
         const int n1[1] = {N}, k1[1] = {K};
-        return gemm_tn_group_impl(1, a1, b1, c1, n1, k1, M, true, stream);
+        return gemm_tn_group_impl(1, a1, b1, c1, n1, k1, M, true, false, stream);
     }
     TIC_REQUIRE(M >= 1 && N % 8 == 0 && K % 8 == 0 && N >= 8 && K >= 8, "gemm_tn: need N, K multiples of 8 (M=%d N=%d K=%d)", M, N, K);
     TIC_REQUIRE(TIC_ALIGNED16(A) && TIC_ALIGNED16(B), "gemm_tn: operands must be 16-byte aligned");
@@ -414,10 +431,16 @@ extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, i
 // occupy the chip; otherwise one split-M launch per problem
 extern "C" int tic_gemm_tn_group_bf16(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N,
                                       const int* K, int M, tic_stream_t stream) {
-    return gemm_tn_group_impl(nprob, A, B, C, N, K, M, false, stream);
+    return gemm_tn_group_impl(nprob, A, B, C, N, K, M, false, false, stream);
+}
+// overwrite != 0: C_g = dY_g^T X_g -- what C held is dropped (it need not be initialised).  One workgroup per full-M tile stores its
+// tile; every other route (stream-K shares, row parts, the split-M 128x128 kernel) adds partial tiles, so C is zeroed first.
+extern "C" int tic_gemm_tn_group_bf16_ex(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N,
+                                         const int* K, int M, int overwrite, tic_stream_t stream) {
+    return gemm_tn_group_impl(nprob, A, B, C, N, K, M, false, overwrite != 0, stream);
 }
 static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const* B, float* const* C, const int* N, const int* K, int M,
-                              bool force256, tic_stream_t stream) {
+                              bool force256, bool overwrite, tic_stream_t stream) {
     TIC_REQUIRE(nprob >= 1 && nprob <= TN_MAX_GROUP && A && B && C && N && K && M >= 1, "gemm_tn_group: bad argument (nprob=%d)", nprob);
     bool ok256 = true;
     int tiles = 0;
@@ -428,6 +451,10 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
         if (N[g] % 256 || K[g] % 256) ok256 = false;
         tiles += (N[g] / 256) * (K[g] / 256);
     }
+    auto zero_all = [&]() -> int {
+        for (int g = 0; g < nprob; ++g) TIC_RT_MEMSET(C[g], 0, (size_t)N[g] * K[g] * 4, stream);
+        return TIC_OK;
+    };
     if (ok256 && g_opt_gemm_tile != 128 && (force256 || g_opt_gemm_tile == 256 || (tiles >= 96 && M >= 512))) {
         GemmTnGroupParams gp;
         memset(&gp, 0, sizeof(gp));
@@ -460,6 +487,7 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
         // 166 vs 175 at M = 6304, 331 vs 288 at M = 12608)
         const bool streamk = g_opt_tn_streamk && (force256 || g_opt_tn_streamk > 1 || nsteps >= g_opt_tn_streamk_min_steps);
         if (streamk && (long)t * nsteps >= shares) {
+            if (overwrite) TIC_TRY(zero_all());   // partial tiles are ADDED
             // phase-aligned split when the tiles divide over the 8 XCDs and the tail workgroups get whole tiles
             int s_main = 0, tpx = 0, tail_each = 0;
             if (g_opt_tn_phase && shares % 8 == 0 && t % 8 == 0) {
@@ -523,6 +551,7 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
         }
 #ifdef TIC_MEASURE
         if (g_opt_gemm_dbg) {
+            if (overwrite) TIC_TRY(zero_all());
 #define TIC_DBG_CASE(D)                                                                   \
     case D:                                                                               \
         TIC_RT_MAX_LDS(gemm_tn256_kernel<D>, G256_LDS_BYTES);                             \
@@ -536,12 +565,18 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
             return tic_after_launch("gemm_tn_group(dbg)");
         }
 #endif
-        TIC_RT_MAX_LDS(gemm_tn256_kernel<0>, G256_LDS_BYTES);
         if (!force256) TIC_RT_TIMER_MARK(0, stream);
-        TIC_LAUNCH(gemm_tn256_kernel<0>, t, 512, G256_LDS_BYTES, stream, gp);
+        if (overwrite) {
+            TIC_RT_MAX_LDS(gemm_tn256_store_kernel, G256_LDS_BYTES);
+            TIC_LAUNCH(gemm_tn256_store_kernel, t, 512, G256_LDS_BYTES, stream, gp);
+        } else {
+            TIC_RT_MAX_LDS(gemm_tn256_kernel<0>, G256_LDS_BYTES);
+            TIC_LAUNCH(gemm_tn256_kernel<0>, t, 512, G256_LDS_BYTES, stream, gp);
+        }
         if (!force256) TIC_RT_TIMER_MARK(1, stream);
         return tic_after_launch("gemm_tn_group");
     }
+    if (overwrite) TIC_TRY(zero_all());
     for (int g = 0; g < nprob; ++g) TIC_TRY(tic_gemm_tn_bf16(A[g], B[g], C[g], M, N[g], K[g], stream));
     return TIC_OK;
 }
@@ -1220,6 +1255,30 @@ extern "C" int tic_vit_refresh_weights(const TicVitState* st, int transposes_onl
 // AdamW over the replica's flat buffers with BOTH bf16 operand copies written in the same pass (torch.optim.AdamW semantics of tic_adamw:
 // TIC/ViT/ntrain.py:39-41, one parameter group, decoupled weight decay on every parameter): the four Linear matrices of every block tile by
 // tile (adamw_tiles_kernel: fp32 update + w16 + wT16), everything else by the flat rule.  After it tic_vit_refresh_weights has nothing to do.
+// the stretches of the parameter / gradient buffer outside the per-layer weight matrices (elementwise.h RestGaps)
+static int vit_rest_gaps(const VitCtx& c, RestGaps& z) {
+    const TicVitLayout& y = c.lay;
+    const long R[4] = {3 * c.D, c.D, c.F, c.D}, C[4] = {c.D, c.D, c.D, c.F};
+    long lo[4] = {y.wqkv, y.wo, y.w1, y.w2}, hi[4];
+    for (int i = 0; i < 4; ++i) hi[i] = lo[i] + R[i] * C[i];
+    for (int i = 0; i < 4; ++i)   // by start offset
+        for (int j = i + 1; j < 4; ++j)
+            if (lo[j] < lo[i]) {
+                const long a = lo[i], b = hi[i];
+                lo[i] = lo[j]; hi[i] = hi[j]; lo[j] = a; hi[j] = b;
+            }
+    z.l0 = y.layer0; z.stride = y.layer_stride; z.nlayers = c.L; z.n = y.n_params;
+    long at = 0;
+    for (int k = 0; k < 5; ++k) {
+        const long end = k < 4 ? lo[k] : y.layer_stride;
+        TIC_REQUIRE(end >= at && at % 4 == 0 && end % 4 == 0, "vit: unexpected parameter layout (matrix ranges overlap or are unaligned)");
+        z.lo[k] = at; z.len[k] = end - at;
+        if (k < 4) at = hi[k];
+    }
+    TIC_REQUIRE(y.layer0 % 4 == 0 && y.n_params % 4 == 0 && y.layer_stride % 4 == 0, "vit: unexpected parameter layout");
+    return TIC_OK;
+}
+
 extern "C" int tic_vit_adamw(const TicVitState* st, float* m, float* v, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                              tic_stream_t s) {
     VitCtx c;
@@ -1231,7 +1290,8 @@ extern "C" int tic_vit_adamw(const TicVitState* st, float* m, float* v, float lr
     AdamwHyper h;
     h.lr = lr; h.b1 = beta1; h.b2 = beta2; h.eps = eps; h.wd = weight_decay; h.inv_bc1 = (float)(1.0 / bc1); h.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     CastTransposeGroup gp;
-    AdamwSkip sk;
+    RestGaps gaps;
+    TIC_TRY(vit_rest_gaps(c, gaps));
     const long in_off[4] = {y.wqkv, y.wo, y.w1, y.w2}, out_off[4] = {y.t_wqkv, y.t_wo, y.t_w1, y.t_w2};
     const long R[4] = {3 * c.D, c.D, c.F, c.D}, C[4] = {c.D, c.D, c.D, c.F};
     int tiles = 0;
@@ -1239,13 +1299,27 @@ extern "C" int tic_vit_adamw(const TicVitState* st, float* m, float* v, float lr
         gp.in_off[i] = y.layer0 + in_off[i]; gp.out_off[i] = out_off[i]; gp.R[i] = (int)R[i]; gp.C[i] = (int)C[i];
         tiles += (int)((R[i] / 64) * (C[i] / 64));
         gp.tile_end[i] = tiles;
-        sk.lo[i] = in_off[i]; sk.hi[i] = in_off[i] + R[i] * C[i];
     }
     gp.in_stride = y.layer_stride; gp.out_stride = y.t_layer_stride;
-    sk.l0 = y.layer0; sk.stride = y.layer_stride; sk.nlayers = c.L;
     TIC_LAUNCH(adamw_tiles_kernel, dim3(tiles, (unsigned)c.L), 256, 64 * CT_STRIDE * 2, s, c.P, c.G, m, v, c.W16, c.WT, gp, h);
-    TIC_LAUNCH(adamw_rest_kernel, ew_grid(y.n_params / 4), 256, 0, s, c.P, c.G, m, v, c.W16, y.n_params / 4, sk, h);
+    TIC_LAUNCH(adamw_rest_kernel, dim3((unsigned)c.L + 2, 5), 256, 0, s, c.P, c.G, m, v, c.W16, gaps, h);
     return tic_after_launch("vit_adamw");
+}
+
+// Clears the gradient buffer before a backward.  keep_matrices != 0: the ranges of the per-layer weight matrices (99.7 % of ViT-L) are
+// left as they are -- for a backward that stores them (tic_vit_backward_layer_ex(..., 1, ...)); everything else is zeroed.
+extern "C" int tic_vit_zero_grads(const TicVitState* st, int keep_matrices, tic_stream_t s) {
+    VitCtx c;
+    TIC_TRY(vit_ctx(st, c));
+    const TicVitLayout& y = c.lay;
+    if (!keep_matrices) {
+        TIC_RT_MEMSET(c.G, 0, (size_t)y.n_params * 4, s);
+        return tic_after_launch("vit_zero_grads");
+    }
+    RestGaps z;
+    TIC_TRY(vit_rest_gaps(c, z));
+    TIC_LAUNCH(zero_gaps_kernel, dim3((unsigned)c.L + 2, 5), 256, 0, s, c.G, z);
+    return tic_after_launch("vit_zero_grads");
 }
 
 static int vit_forward_impl(const TicVitState* st, const float* x, float* logits_out, bool infer, tic_stream_t s);
@@ -1309,7 +1383,11 @@ extern "C" int tic_vit_backward_head(const TicVitState* st, const float* dlogits
     return TIC_OK;
 }
 
-extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stream_t s) {
+extern "C" int tic_vit_backward_layer_ex(const TicVitState* st, int layer, int overwrite_dw, tic_stream_t s);
+extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stream_t s) { return tic_vit_backward_layer_ex(st, layer, 0, s); }
+// overwrite_dw != 0: the four weight-matrix gradients of the block are STORED, not accumulated (their ranges of the gradient buffer need
+// not be zero: tic_vit_zero_grads(st, 1, ...) leaves them alone); everything else (biases, LayerNorm) still accumulates
+extern "C" int tic_vit_backward_layer_ex(const TicVitState* st, int layer, int overwrite_dw, tic_stream_t s) {
     VitCtx c;
     TIC_TRY(vit_ctx(st, c));
     TIC_REQUIRE(layer >= 0 && layer < c.L, "vit_backward_layer: layer %d out of range", layer);
@@ -1346,7 +1424,7 @@ extern "C" int tic_vit_backward_layer(const TicVitState* st, int layer, tic_stre
         const void* gB[4] = {a + y.g, a + y.a2, a + y.o, a + y.a1};
         float* gC[4] = {lg + y.w2, lg + y.w1, lg + y.wo, lg + y.wqkv};
         const int gN[4] = {D, F, D, 3 * D}, gK[4] = {F, D, D, D};
-        TIC_TRY(tic_gemm_tn_group_bf16(4, gA, gB, gC, gN, gK, M, s));
+        TIC_TRY(tic_gemm_tn_group_bf16_ex(4, gA, gB, gC, gN, gK, M, overwrite_dw, s));
     }
     TIC_TRY(tic_layernorm_bwd_ex(da, hin, D, lp + y.ln1_g, (float*)(a + y.mean1), (float*)(a + y.rstd1), dh, dh, dhb, lg + y.ln1_g, lg + y.ln1_b,
                                  l > 0 ? c.G + y.layer0 + (l - 1) * y.layer_stride + y.b2 : nullptr, M, D, s));

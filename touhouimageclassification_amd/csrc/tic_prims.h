@@ -62,6 +62,11 @@ TIC_DEV bf16x4 lds_tr64_hidden(uint32_t addr, uint32_t imm) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(imm));
     return r;
 }
+TIC_DEV bf16x8 lds_ld128_hidden(uint32_t addr, uint32_t imm) {
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(imm));
+    return r;
+}
 // N = LDS operations that may still be outstanding (they return in order): lds_wait<8>(...) after 8 + 8 reads has the first 8 landed
 template <int N = 0>
 TIC_DEV void lds_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {

@@ -224,10 +224,27 @@ class VitEngine:
         (self._slot_infer.add if infer else self._slot_infer.discard)((B, slot))
         return logits, (B, slot, self._gen)
 
+    def zero_grads(self, B: int, keep_matrices: bool = False) -> None:
+        """optimizer.zero_grad() for the flat gradient buffer.  keep_matrices: the per-layer weight-matrix ranges (99.7 % of ViT-L) are
+        left alone and the NEXT full backward stores those gradients instead of accumulating into them -- no 1.2 GB zeroing pass and no
+        read of the old values in the weight-gradient kernels' epilogues."""
+        if not keep_matrices:
+            self.grads.zero_()
+            self._dw_overwrite = False
+            return
+        _, st, _ = self._state(B, (self._slot_next.get(B, 1) - 1) % max(1, self.live_graphs))
+        self.backend.call("tic_vit_zero_grads", ctypes.byref(st), 1, self.backend.stream())
+        self._dw_overwrite = True
+
     def backward(self, dlogits: torch.Tensor, bucket_hook: Optional[Callable[[str, int, int], None]] = None,
                  head_only: bool = False, stamp: Optional[Tuple[int, int, int]] = None) -> None:
-        """Accumulates into self.grads.  bucket_hook(name, start, end) fires as each bucket's gradients are
+        """Accumulates into self.grads (after zero_grads(keep_matrices=True): stores the weight-matrix gradients, accumulates the rest).
+        bucket_hook(name, start, end) fires as each bucket's gradients are
         complete (enqueued) so a data-parallel wrapper can all-reduce it while earlier layers still run."""
+        overwrite = 1 if getattr(self, "_dw_overwrite", False) else 0
+        if overwrite and head_only:
+            raise RuntimeError("TIC ViT backward: zero_grads(keep_matrices=True) must be followed by a FULL backward (it leaves the matrix "
+                               "gradients undefined until one has stored them)")
         B = dlogits.shape[0]
         if stamp is None:   # fused step: the forward that just ran
             slot = (self._slot_next.get(B, 1) - 1) % max(1, self.live_graphs)
@@ -253,10 +270,11 @@ class VitEngine:
         if head_only:
             return
         for j, i in enumerate(reversed(range(self.L))):
-            self.backend.call("tic_vit_backward_layer", ctypes.byref(st), i, s)
+            self.backend.call("tic_vit_backward_layer_ex", ctypes.byref(st), i, overwrite, s)
             if bucket_hook:
                 bucket_hook(*bk[1 + j])
         self.backend.call("tic_vit_backward_embed", ctypes.byref(st), s)
+        self._dw_overwrite = False
         if bucket_hook:
             bucket_hook(*bk[-1])
 

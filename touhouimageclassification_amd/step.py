@@ -26,7 +26,7 @@ def fused_train_step(model, optimizer: FusedAdamW, x: torch.Tensor, target: torc
     e.backend.call("tic_softmax_xent", logits.data_ptr(), tgt.data_ptr() if hard else None, None if hard else tgt.data_ptr(),
                    loss.data_ptr(), dlogits.data_ptr(), B, C, sync.grad_scale if sync else 1.0, e.backend.stream())
     loss = loss[0]
-    e.grads.zero_()
+    e.zero_grads(B, keep_matrices=True)   # this step's backward is the only writer: it stores the weight-matrix gradients whole
     hook = None
     if model._bucket_hook is not None:
         user = model._bucket_hook
