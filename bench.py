@@ -449,7 +449,7 @@ def main():
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section); only valid for
         # the kernel source it was measured on: the record carries the hash of csrc/gemm_tn256.h and goes stale (null) with any edit
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tf = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if os.path.exists(tf):
             rec = json.load(open(tf))
             src = os.path.join(ROOT, "touhouimageclassification_amd", "csrc", "gemm_tn256.h")

@@ -113,6 +113,21 @@ def test_gemm_tn_group_phase_aligned_split(env, mfma):
         call("tic_set_option", b"tn_mfma", 0)
 
 
+def test_gemm_tn_group_four_wave_experiment(env):
+    """the measured-and-rejected 4-wave x 128 x 128 form of the stream-K launch (gemm_tn256_w4.h, simulator + measurement builds only,
+    DESIGN 4c: 685 vs 1 231 TFLOP/s): same results as the shipped kernel's checks, flat and phase-aligned shares, ragged last step"""
+    call("tic_set_option", b"gemm_tile", 256)
+    call("tic_set_option", b"tn_waves", 4)
+    try:
+        for shares in (16, 7):
+            call("tic_set_option", b"tn_streamk", shares)
+            kc.check_gemm_tn_group(env, 333, [(512, 512), (256, 1024)])
+    finally:
+        call("tic_set_option", b"tn_waves", 8)
+        call("tic_set_option", b"gemm_tile", 0)
+        call("tic_set_option", b"tn_streamk", 1)
+
+
 @pytest.mark.parametrize("parts", [2, 3])
 def test_gemm_tn_group_equal_parts_split(env, parts):
     """9 tiles (not a multiple of 8: XCD runs of 2 and 1 tiles), every tile cut into 2 / 3 equal row ranges; 333 rows = 6 steps"""

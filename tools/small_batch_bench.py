@@ -60,7 +60,7 @@ def main():
             row = []
             # ring = the 4-stage form of the 128x128 kernel (gemm.h NST = 4); forcing it on / off needs the measurement library
             # (TIC_HIP_LIB=.../libtic_hip_dbg.so); the product library chooses by itself ("auto")
-            cfgs = (("128", 128, 0, 0), ("128r", 128, 0, 1), ("128/2", 128, 2, 0), ("128r/2", 128, 2, 1), ("128r/4", 128, 4, 1), ("256", 256, 0, -1), ("auto", 0, -1, -1))
+            cfgs = (("128", 128, 0, 0), ("128r", 128, 0, 1), ("128/2", 128, 2, 0), ("128r/2", 128, 2, 1), ("128r/4", 128, 4, 1), ("256", 256, 0, -1), ("256/2", 256, 2, -1), ("auto", 0, -1, -1))
             for label, tile, sp, ring in cfgs:
                 call("tic_set_option", b"gemm_tile", tile)
                 call("tic_set_option", b"gemm_split", sp)

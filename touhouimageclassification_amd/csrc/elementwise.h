@@ -223,8 +223,8 @@ __global__ void __launch_bounds__(256) adamw_tiles_kernel(float* __restrict__ p,
     }
 }
 // The element ranges OUTSIDE the per-layer weight matrices (biases, LayerNorm, embeddings, head: 0.3 % of ViT-L), as a launch grid:
-// grid (L + 2, 5): block (l, k) walks gap k of layer l (the <= 5 stretches between / around its four matrices); x = L walks [0, l0),
-// x = L + 1 walks [l0 + L * stride, n) (there y strides).  Every boundary is a multiple of 8 elements (tic_vit_layout pads).
+// grid (L + 2, 5 x parts): blocks (l, k + 5 j) walk gap k of layer l (the <= 5 stretches between / around its four matrices); x = L walks
+// [0, l0), x = L + 1 walks [l0 + L * stride, n) (there all of y strides).  Every boundary is a multiple of 8 elements (tic_vit_layout pads).
 // (The first version tested every float4 of the whole buffer against the ranges with a 64-bit modulo: 82 us for 0.3 % of the bytes.)
 struct RestGaps {
     long l0, stride, nlayers, n;
@@ -235,8 +235,11 @@ TIC_DEV void rest_range(const RestGaps& z, long& start, long& n4, long& first, l
     first = TIC_TID;
     step = 256;
     if (x < z.nlayers) {
-        start = z.l0 + x * z.stride + z.lo[TIC_BID_Y];
-        n4 = z.len[TIC_BID_Y] / 4;
+        const int k = TIC_BID_Y % 5, part = TIC_BID_Y / 5, parts = TIC_NBLK_Y / 5;   // grid.y = 5 x parts
+        start = z.l0 + x * z.stride + z.lo[k];
+        n4 = z.len[k] / 4;
+        first += (long)part * 256;
+        step *= parts;
     } else {
         start = (x == z.nlayers) ? 0 : z.l0 + z.nlayers * z.stride;
         n4 = ((x == z.nlayers) ? z.l0 : z.n - start) / 4;

@@ -1302,7 +1302,7 @@ extern "C" int tic_vit_adamw(const TicVitState* st, float* m, float* v, float lr
     }
     gp.in_stride = y.layer_stride; gp.out_stride = y.t_layer_stride;
     TIC_LAUNCH(adamw_tiles_kernel, dim3(tiles, (unsigned)c.L), 256, 64 * CT_STRIDE * 2, s, c.P, c.G, m, v, c.W16, c.WT, gp, h);
-    TIC_LAUNCH(adamw_rest_kernel, dim3((unsigned)c.L + 2, 5), 256, 0, s, c.P, c.G, m, v, c.W16, gaps, h);
+    TIC_LAUNCH(adamw_rest_kernel, dim3((unsigned)c.L + 2, 5 * 8), 256, 0, s, c.P, c.G, m, v, c.W16, gaps, h);
     return tic_after_launch("vit_adamw");
 }
 
@@ -1318,7 +1318,7 @@ extern "C" int tic_vit_zero_grads(const TicVitState* st, int keep_matrices, tic_
     }
     RestGaps z;
     TIC_TRY(vit_rest_gaps(c, z));
-    TIC_LAUNCH(zero_gaps_kernel, dim3((unsigned)c.L + 2, 5), 256, 0, s, c.G, z);
+    TIC_LAUNCH(zero_gaps_kernel, dim3((unsigned)c.L + 2, 5 * 8), 256, 0, s, c.G, z);
     return tic_after_launch("vit_zero_grads");
 }
 
