@@ -33,3 +33,18 @@ except Exception:
     bws = float("nan")
 print(f"B={B}: bwd (q,k bias grad via scratch, v skipped) {bws:7.1f} us")
 print(f"B={B}: attn fwd {fwd:7.1f} us   bwd (+bias grad) {bwd:7.1f} us   bwd (no bias grad) {bwd0:7.1f} us", flush=True)
+# interleaved A/B of the tile-to-wave assignment (measurement library only: TIC_HIP_LIB=.../libtic_hip_dbg.so)
+try:
+    call("tic_set_option", b"attn_legacy", 0)
+    run = lambda: call("tic_attention_bwd_ws", qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), do.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), part.data_ptr(), 1, B, H, N, 0.125, current_stream())
+    rows = {0: [], 1: []}
+    for rnd in range(4):
+        for legacy in (1, 0):
+            call("tic_set_option", b"attn_legacy", legacy)
+            rows[legacy].append(t(run))
+    call("tic_set_option", b"attn_legacy", 0)
+    for legacy in (1, 0):
+        v = sorted(rows[legacy])
+        print(f"B={B}: bwd, {'round-1 assignment (waves 0-7 phase A, 8-15 phase B)' if legacy else 'one A tile per wave + B tiles on the rest      '}: median {0.5 * (v[1] + v[2]):7.1f} us  ({', '.join(f'{x:.1f}' for x in rows[legacy])})")
+except Exception as e:   # product library: no such knob
+    print("(no attn_legacy knob in this library)")

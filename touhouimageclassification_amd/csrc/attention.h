@@ -34,6 +34,7 @@ struct AttnParams {
     bf16_t* dqkv;        // [M, 3D]       (bwd out)
     float* dbias;        // [3D] optional (bwd): += column sums of dqkv = gradient of the fused q/k/v bias
     int skip_v_bias;     // bwd: the v third of dbias is produced elsewhere (= column sums of dO, because the rows of P sum to 1)
+    int legacy_assign;   // bwd, test / measurement builds: the round-1 tile-to-wave assignment (A/B)
     float* dbias_part;   // [B][3D] optional (bwd): per-image column sums, PLAIN stores (no atomics); reduced by attn_dbias_reduce_kernel
     int B, H, N, D;      // D = H * 64
     float scale;
@@ -168,11 +169,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) attn_fwd_kernel(Attn
 }
 
 // LDS: Q | K | V | dO tiles, then lse[224] and delta[224] floats
-#define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4 + 8 * 3 * ATT_HD * 4)   // + q/k/v bias-gradient sums: 8 wave slots x [3][64]
+#define ATT_BWD_LDS (4 * ATT_TILE_BYTES + 2 * ATT_ROWS * 4 + 16 * 3 * ATT_HD * 4)   // + q/k/v bias-gradient sums: 16 wave slots x [3][64]
 
-// 16 waves: waves 0-7 run phase A (dK, dV), waves 8-15 run phase B (dQ) CONCURRENTLY -- both only read the LDS tiles and
-// write disjoint outputs, so every SIMD hosts two waves of each phase and their latencies overlap (the 13 key tiles /
-// 13 query blocks of a head are dealt to 8 waves each: critical path 2 tiles instead of 4).
+// 16 waves run phase A (dK, dV: one 16-key tile) and phase B (dQ: 16-query blocks) tiles CONCURRENTLY -- both only read the LDS tiles
+// and write disjoint outputs, so every SIMD hosts waves of either phase and their latencies overlap; the assignment of the 13 + 13
+// tiles of a head to the 16 waves is explained where it is made.
 __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     const int l = lane_id(), w = wave_id(), tid = TIC_TID;
     const int bh = TIC_BID_X, b = bh / p.H, h = bh - b * p.H;
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
             lds_stf(DEL + 4u * row, dl);
         }
     }
-    for (int i = tid; i < 8 * 3 * ATT_HD; i += 1024) lds_stf(DBL + 4u * (uint32_t)i, 0.f);
+    for (int i = tid; i < 16 * 3 * ATT_HD; i += 1024) lds_stf(DBL + 4u * (uint32_t)i, 0.f);
     wait_vmcnt0();
     block_sync();
 
@@ -238,7 +239,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
     // q/k/v bias gradient = column sums of dq / dk / dv.  Every finished tile is reduced at once: 16-lane rows by DPP, then the
     // wave adds into ITS OWN LDS slot (lane 0 of each row, read-modify-write, no atomics: phase-A wave w and phase-B wave
     // w + 8 share slot w on disjoint columns).  Carrying per-lane partial sums across the tiles cost 32 VGPRs kernel-wide.
-    const uint32_t slot = DBL + (uint32_t)(w & 7) * (3u * ATT_HD * 4u);
+    const uint32_t slot = DBL + (uint32_t)w * (3u * ATT_HD * 4u);
     auto reduce_cols = [&](const f32x4 (&part)[4], uint32_t col0) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -251,8 +252,23 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
                 }
             }
     };
-    if (w < 8)
-    for (int kt = w; kt < n16; kt += 8) {
+    // Tile-to-wave assignment (round 3).  Waves 0-7 used to own phase A and waves 8-15 phase B, 13 tiles each: five waves of either
+    // half ran two tiles, and the workgroup -- alone on its CU -- lasted two phase-A tiles = 2.67 phase-B units (a phase-A tile costs
+    // about 4/3 of a phase-B tile) while the average wave had 1.9.  Now every wave w < n16 takes ONE phase-A tile, the 16 - n16 waves
+    // without one take two phase-B tiles each and the remaining phase-B tiles go one each to waves 0, 1, ...: the longest wave runs one
+    // A + one B = 2.33 units.  (p.legacy_assign: the old assignment, for A/B measurements -- test / measurement builds only.)
+    bool a_on = w < n16;
+    int a_stride = 16, b0 = (w >= n16) ? 2 * (w - n16) : 2 * (16 - n16) + w, b1 = (w >= n16) ? b0 + 1 : ATT_ROWS;
+#if defined(TIC_MEASURE) || defined(TIC_SIM)
+    if (p.legacy_assign) {
+        a_on = w < 8;
+        a_stride = 8;
+        b0 = w >= 8 ? w - 8 : ATT_ROWS;
+        b1 = w >= 8 ? 8 + ((0x74362105 >> ((w & 7) * 4)) & 7) : ATT_ROWS;   // second tiles to waves 9, 10, 11, 13, 14: SIMD loads 4A+2B, 3A+4B, 3A+4B, 3A+3B
+    }
+#endif
+    if (a_on)
+    for (int kt = w & (a_stride - 1); kt < n16; kt += a_stride) {
         const int key = kt * 16 + li;
         const bool key_ok = key < N;
         bf16x8 fk[2], fv[2];
@@ -326,14 +342,10 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
         }
     }
 
-    // ---------------- phase B: dQ (query on the lane) -- waves 8..15 ----------------
-    // Which waves take a SECOND tile decides the load of the four SIMDs (wave w runs on SIMD w % 4; a phase-A tile costs about
-    // 4/3 of a phase-B tile).  Phase A gives its 5 second tiles to waves 0-4 (SIMD loads 4,3,3,3 tiles); if phase B did the
-    // same (waves 8-12) SIMD 0 would carry 4A + 4B against 3A + 3B elsewhere.  With phase B's second tiles on waves 9, 10, 11, 13,
-    // 14 the loads are 4A+2B, 3A+4B, 3A+4B, 3A+3B: the critical SIMD drops from 9.3 to 8 B-tile units.
-    const int rank2 = (0x74362105 >> ((w & 7) * 4)) & 7;   // order in which waves 8..15 receive tiles 8, 9, ...: 9,10,11,13,14,8,12,15
-    if (w >= 8)
-    for (int it = 0, qb16 = w - 8; it < 2 && qb16 < n16; ++it, qb16 = 8 + rank2) {
+    // ---------------- phase B: dQ (query on the lane) ----------------
+    for (int it = 0; it < 2; ++it) {
+        const int qb16 = it ? b1 : b0;
+        if (qb16 >= n16) continue;   // wave-uniform
         const int q = qb16 * 16 + li;
         bf16x8 fq[2], fd[2];
 #pragma unroll
@@ -399,7 +411,7 @@ __global__ void __launch_bounds__(1024, 4) attn_bwd_kernel(AttnParams p) {
         if (tid < 3 * ATT_HD) {
             float v = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v += lds_ldf(DBL + (uint32_t)k * (3u * ATT_HD * 4u) + 4u * tid);
+            for (int k = 0; k < 16; ++k) v += lds_ldf(DBL + (uint32_t)k * (3u * ATT_HD * 4u) + 4u * tid);
             const int col = (tid >> 6) * D + h * ATT_HD + (tid & 63);
             // 5 312 workgroups x 192 atomics on 3 072 addresses cost ~25 % of this kernel: with a partial buffer each
             // (image, head) stores its own 192 sums and a tiny second kernel adds the images up

@@ -98,6 +98,7 @@ static int g_opt_tn_mfma = 0;     // MFMA shape of the grouped dW stream-K launc
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 #if defined(TIC_SIM) || defined(TIC_MEASURE)
 static int g_opt_tn_waves = 8;   // experiment: 4 = the one-wave-per-SIMD form of the grouped dW tile (gemm_tn256.h tn256_tile_segment16_w4)
+static int g_opt_attn_legacy = 0;   // test / measurement builds: attention backward with the round-1 tile-to-wave assignment
 static int g_opt_nt_deep = -1;    // test / measurement builds: 4-stage form of the 128x128 NT kernel: -1 auto (<= 256 workgroups), 0 never, 1 always
 static int g_opt_nt_fault = 0;   // test builds: part 0 of every split tile withholds its flag (exercises the timeout report of flag_wait)
 #endif
@@ -132,6 +133,10 @@ extern "C" int tic_set_option(const char* name, int value) {
 #if defined(TIC_SIM) || defined(TIC_MEASURE)
     if (name && !strcmp(name, "tn_waves") && (value == 4 || value == 8)) {
         g_opt_tn_waves = value;
+        return TIC_OK;
+    }
+    if (name && !strcmp(name, "attn_legacy") && (value == 0 || value == 1)) {
+        g_opt_attn_legacy = value;
         return TIC_OK;
     }
     if (name && !strcmp(name, "nt_deep") && value >= -1 && value <= 1) {
@@ -678,6 +683,9 @@ static int attention_bwd_launch(const void* qkv, const void* o, const float* lse
     p.B = B; p.H = H; p.N = N; p.D = H * 64; p.scale = scale;
     p.dbias_part = dbias ? dbias_part : nullptr;
     p.skip_v_bias = (dbias && skip_v_bias) ? 1 : 0;
+#if defined(TIC_SIM) || defined(TIC_MEASURE)
+    p.legacy_assign = g_opt_attn_legacy;
+#endif
     TIC_RT_MAX_LDS(attn_bwd_kernel, ATT_BWD_LDS);
     TIC_LAUNCH(attn_bwd_kernel, B * H, 1024, ATT_BWD_LDS, stream, p);
     if (p.dbias_part) {   // the scratch rows keep the [3D] stride; with skip_v_bias only the q and k thirds are summed
