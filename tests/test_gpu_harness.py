@@ -207,7 +207,7 @@ def test_resnet_harness_steps_and_train_model(tmp_path):
     from touhouimageclassification_amd.ResNet import train as rt
     from touhouimageclassification_amd.ResNet.model import resnet18
     C, img = 10, 64
-    rc.check_teacher_forced_steps(rt, None, DEV, C=C, B=32, img=img, tol=dict(loss=1e-2, gnorm=0.13, fc=0.05, cos=0.90, stats=1.5e-2, rerun=1e-4))
+    rc.check_teacher_forced_steps(rt, None, DEV, C=C, B=32, img=img, tol=dict(loss=1e-2, gnorm=0.14, fc=0.05, cos=0.90, stats=1.5e-2, rerun=1e-4))
     # the loop: two epochs, (model_sd, optim_sd, sched_sd) checkpoints, scheduler stepped per epoch
     ds = _FloatSet(40, size=img, C=C, seed=5)
     m2, o2, s2, c2 = rt.build_reference_setup(C, lr=5e-2, arch=resnet18)
