@@ -273,3 +273,13 @@ def test_vit_base_step_at_config2_batch_ties_to_oracle_and_to_small_batches():
     fused_train_step(model, opt, xd, yd, None)
     moved = (e.params - before).abs()
     assert float(moved.max()) <= 1.3e-5 and all(float(moved[a:b].max()) > 0 for _, a, b in e.buckets())
+
+
+def test_resnet50_step_at_config4_batch_ties_to_the_oracle():
+    """BASELINE config 4 at its full size -- ResNet-50 @224, 256 images (M = 802 816 rows in the first stage: the implicit stem, the 3x3
+    implicit GEMMs, the parity-class stride-2 input gradients, the 256x256 and slab routes of the 1x1 weight gradients, BatchNorm
+    reductions over 512 row splits) -- one training step against the fp32 oracle run on the same device.  Bands as the 32-image golden
+    case of the same model (tests/test_gpu_resnet.py): what they bound is bf16 storage noise through 50 layers, not the batch size."""
+    from tests import resnet_checks as rc
+    rc.check_against_live_oracle("resnet50_b256", "resnet50", 120, 256, 224, torch.device("cuda"),
+                                 dict(logits=4.5e-2, loss=1e-2, gnorm=0.18, fc=0.05, cos=0.69, stats=1.5e-2))

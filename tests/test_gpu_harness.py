@@ -293,6 +293,46 @@ def _moe(E, C, seed=11):
                        gate_model_name="tiny")
 
 
+def test_sparse_dispatch_equals_dense_mixture_at_config5_size():
+    """BASELINE config 5 at the reference's size on one GPU -- 8 ViT-B/16 experts + a ViT-B/16 gate, 120 classes, top-2, 32 images
+    (TIC/ResMoE/model.py:60-72, train.py:150-176).  `sparse=True` evaluates each expert on the ~8 images routed to it; the reference
+    evaluates all 8 on all 32 and multiplies six of them by exact zeros.  Same mixture: identical routing, gate weights equal, logits
+    and the gradients of every expert head and of the gate equal up to the bf16 rounding of GEMMs that ran at another row count."""
+    from touhouimageclassification_amd.ResMoE.model import make_ViTMoE
+    from touhouimageclassification_amd.ResMoE import train as mt
+    E, C, B = 8, 120, 32
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 3, 224, 224, generator=g).to(DEV)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, C, (B,), generator=g), C).float().to(DEV)
+    res = []
+    for sparse in (False, True):
+        torch.manual_seed(21)
+        m = make_ViTMoE(num_classes=C, num_experts=E, top_k=2, gateway_t=0.01, pretrained=False, model_name="google/vit-base-patch16-224",
+                        gate_pretrained=False).to(DEV)
+        m.eval()              # deterministic gate (training mode adds noise to the gate logits)
+        with torch.no_grad():   # a freshly initialised gate head sends (nearly) every image to the same two experts: spread the routing
+            w = torch.randn(m.gate.vit.classifier.weight.shape, generator=torch.Generator().manual_seed(5)) * 2.0
+            m.gate.vit.classifier.weight.copy_(w.to(DEV))
+        m.sparse = sparse
+        logits, gw, idx = m(x)
+        mt.total_loss(logits, tgt, gw, idx).backward()
+        grad = lambda p: torch.zeros_like(p) if p.grad is None else p.grad.clone()   # noqa: E731  (an expert nobody was routed to never runs)
+        res.append((logits.detach().float(), gw.detach(), idx, [grad(e.classifier.weight) for e in m.experts], grad(m.gate.vit.classifier.weight)))
+        del m
+        torch.cuda.empty_cache()
+    d, s = res
+    assert torch.equal(d[2], s[2]), "routing differs"
+    used = torch.bincount(d[2].flatten(), minlength=E)
+    print("images per expert:", used.tolist())
+    assert int((used > 0).sum()) >= 6 and int(used.max()) <= 24, "routing collapsed: the case would be vacuous"
+    torch.testing.assert_close(s[1], d[1], atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(s[0], d[0], atol=2e-2 * max(1.0, float(d[0].abs().max())), rtol=2e-2)
+    scale = max(float(b.norm()) for b in d[3])
+    for k, (a, b) in enumerate(zip(s[3], d[3])):
+        hr.le(f"expert {k} head gradient, sparse vs dense (rel L2)", float((a - b).norm()), 0.02 * float(b.norm()) + 1e-3 * scale)
+    hr.le("gate head gradient, sparse vs dense (rel L2)", float((s[4] - d[4]).norm() / (d[4].norm() + 1e-12)), 0.02)
+
+
 def test_dense_moe_training_step_matches_oracle():
     """config 5's model, dense form: gate ViT + E expert ViTs + gate/combine/loss kernels, one `training_step` + SGD on the GPU.
     Reference: every ViT through oracle/vit_oracle.py, the mixture arithmetic through oracle/moe_oracle.py, autograd end to end."""

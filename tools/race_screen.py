@@ -41,6 +41,11 @@ print("gemm race screen:", "CLEAN" if bad == 0 else f"{bad} mismatching outputs"
 # stream-K forms add partial tiles with fp32 atomics -> equal to the plain result up to fp32 summation order
 import ctypes
 bad_tn = 0
+try:   # `tn_phase` (flat instead of phase-aligned stream-K shares) is a measurement-library knob (TIC_HIP_LIB=.../libtic_hip_dbg.so)
+    call("tic_set_option", b"tn_phase", 1)
+    HAVE_PHASE_KNOB = True
+except Exception:
+    HAVE_PHASE_KNOB = False
 for (M, shapes) in ((32702, [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 1024)]), (16351, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),
                     (4099, [(256, 512), (512, 256)]), (65, [(256, 256)])):
     As = [torch.randn(M, n, device=dev).to(torch.bfloat16) for n, k in shapes]
@@ -49,7 +54,9 @@ for (M, shapes) in ((32702, [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 10
     PA = (ctypes.c_void_p * G)(*[t.data_ptr() for t in As]); PB = (ctypes.c_void_p * G)(*[t.data_ptr() for t in Bs])
     NN = (ctypes.c_int * G)(*[s_[0] for s_ in shapes]); KK = (ctypes.c_int * G)(*[s_[1] for s_ in shapes])
     def run(streamk, phase):
-        call("tic_set_option", b"gemm_tile", 256); call("tic_set_option", b"tn_streamk", streamk); call("tic_set_option", b"tn_phase", phase)
+        call("tic_set_option", b"gemm_tile", 256); call("tic_set_option", b"tn_streamk", streamk)
+        if HAVE_PHASE_KNOB:
+            call("tic_set_option", b"tn_phase", phase)
         Cs = [torch.zeros(n, k, device=dev) for n, k in shapes]
         PC = (ctypes.c_void_p * G)(*[t.data_ptr() for t in Cs])
         call("tic_gemm_tn_group_bf16", G, PA, PB, PC, NN, KK, M, current_stream())
@@ -72,7 +79,9 @@ for (M, shapes) in ((32702, [(1024, 4096), (4096, 1024), (1024, 1024), (3072, 10
                 err = float((a - b).abs().max() / b.abs().max())
                 if err > 2e-5:
                     print(f"TN MISMATCH stream-K({sk},{ph}) M={M} rep {rep}: rel err {err:.3e}", flush=True); bad_tn += 1
-call("tic_set_option", b"gemm_tile", 0); call("tic_set_option", b"tn_streamk", 1); call("tic_set_option", b"tn_phase", 1)
+call("tic_set_option", b"gemm_tile", 0); call("tic_set_option", b"tn_streamk", 1)
+if HAVE_PHASE_KNOB:
+    call("tic_set_option", b"tn_phase", 1)
 print("dW race screen:", "CLEAN" if bad_tn == 0 else f"{bad_tn} problems", flush=True)
 
 from touhouimageclassification_amd.ViT.model import ViT
