@@ -39,7 +39,9 @@ const char* tic_last_error_string(void);
  * the training step uses).  Unknown names / values return TIC_EINVAL.
  *   "gemm_tile"  0 (auto) | 128 | 256       NT / TN tile family (auto: 256x256 from 128 tiles up)
  *   "gemm_split" -1 (auto) | 0 | 2 | 4      split-K form of the 128x128 NT kernel (needs tic_gemm_nt_scratch; never under stream capture);
- *                                           auto: two parts where 2 x tiles fit 512 workgroups and a part keeps >= 16 K tiles
+ *                                           auto: two parts where both still get a CU of their own (2 x tiles <= 256) and a part keeps >= 16
+ *                                           K tiles.  (Launches of <= 256 workgroups of that kernel, split or not, run its 4-stage LDS-DMA
+ *                                           ring instead of the 2-stage loop: same products in the same order, bit-identical results.)
  *   "tn_streamk" 1 (256 shares) | 0 | n     stream-K split of the grouped dW launch
  *   "tn_parts"   -1 (auto) | 0 | 2..8       grouped dW whose tile count has no phase-aligned split (ViT-B: 108 tiles): every tile in n equal
  *                                           row parts (auto: 256 / tiles) | 0: flat stream-K
