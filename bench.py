@@ -13,7 +13,9 @@ Rank 0 prints ONE JSON line.
                 max |dlogits|, relative loss difference, top-1 / top-5 agreement
   cpu_baseline  the CPU oracle (oracle/vit_oracle.py, a port) timed on this box's host cores, N = 1 only:
                 3 warm-up + 5 timed steps, median; headline config in fp32, `also` = bf16-autocast and BASELINE config 1
-  sweep         per-GPU batch {8, 16, 32, 64, 128} (8 / 16: what the reference's ntrain*.py launchers set; 32-128: SURVEY 8d), outside the headline timed region
+  sweep         per-GPU batch {8, 16, 32, 64, 83, 128, 166} (8 / 16: what the reference's ntrain*.py launchers set; 32-128: SURVEY 8d; 83 / 166:
+                the 1/4 and 1/2 of the headline batch whose 197 x B token rows are again a whole number of 256-row tiles -- what a
+                data-parallel user with a global batch of 664 / 1328 on 8 GPUs should pick), outside the headline timed region
   secondary     N = 1: BASELINE config 2 (ViT-B C=10 batch 256), config 4 (ResNet-50 @224 batch 256), the reference's own ResNet run
                 (ResNet-152 @256 batch 80, TIC/ResNet/train.py:213) and forward-only ViT-L at batch 1 / 64 / 256 -- each with img/s, ms/step
                 and the fraction of the bound it is measured against (ResNet: max of the MFMA time and BatchNorm's 22 B/element at 8 TB/s)
@@ -281,7 +283,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configurations (ViT-B B=256, ResNet-50 / -152, forward-only ViT-L)")
-    ap.add_argument("--sweep", default="8,16,32,64,128", help="per-GPU batch sizes reported beside the headline")
+    ap.add_argument("--sweep", default="8,16,32,64,83,128,166", help="per-GPU batch sizes reported beside the headline")
     ap.add_argument("--autograd", action="store_true", help="drive the step through torch autograd + F.cross_entropy (plugin surface) instead of the fused step")
     ap.add_argument("--aug", action="store_true", help="BASELINE config 3: include the on-GPU augmentation (uint8 256x256 thumbnails -> crop/flip/jitter/gray/erase/normalise) and MixUp/CutMix (soft labels) in every timed step")
     ap.add_argument("--bf16-buckets", action="store_true", help="N > 1: gradient buckets cross the links as bf16 (BucketedGradSync(compress='bf16')); default fp32")
