@@ -119,9 +119,10 @@ def test_fused_bias_gradients(env):
 
 
 
-@pytest.mark.parametrize("M,N,K", [(40960, 1024, 256), (50176, 256, 1024), (12544, 2048, 512), (12544, 512, 2048), (8200, 256, 256), (200704, 512, 256)])
+@pytest.mark.parametrize("M,N,K", [(40960, 1024, 256), (50176, 256, 1024), (12544, 2048, 512), (12544, 512, 2048), (8200, 256, 256), (200704, 512, 256), (20480, 1024, 2048), (50176, 512, 1024)])
 def test_gemm_tn_parts_slab_route(env, M, N, K):
-    """ResNet 1x1 weight-gradient shapes (4 .. 16 tiles over 12 544 .. 200 704 rows): row parts stored to the slab + one reduce launch"""
+    """ResNet 1x1 weight-gradient shapes over 8 200 .. 200 704 rows: from 8 tiles of 256 x 256 on (the 512 <-> 1024 / 2048 layers) row parts
+    stored to the slab + one reduce launch; below (256 <-> 1024: 4 tiles) the split-M 128 x 128 kernel, which is faster there -- same check"""
     kc.check_gemm_tn_slab(env, M, N, K)
 
 

@@ -148,8 +148,13 @@ def test_gemm_tn_group_equal_parts_split(env, parts):
 
 
 def test_gemm_tn_parts_slab_route(env):
-    """2 tiles x 129 steps (ragged last step): 32 row parts per tile store into the slab, one reduce launch adds them to C"""
-    kc.check_gemm_tn_slab(env, 8200, 256, 512, slab_mb=24)
+    """2 tiles x 129 steps (ragged last step): 32 row parts per tile store into the slab, one reduce launch adds them to C
+    (the library takes this route from 8 tiles on; the test knob lowers that so that 2 tiles reach it in the simulator)"""
+    call("tic_set_option", b"tn_slab_min_tiles", 1)
+    try:
+        kc.check_gemm_tn_slab(env, 8200, 256, 512, slab_mb=24)
+    finally:
+        call("tic_set_option", b"tn_slab_min_tiles", 8)
 
 
 @pytest.mark.parametrize("M,N,K,split", [(200, 256, 512, 2), (130, 128, 1024, 4)])

@@ -81,7 +81,26 @@ extern "C" int tic_dbg_launch_log(int i, int* out4) {
 }
 #endif
 static int g_opt_tn_slab = 1;             // few-tile weight gradients: row parts stored to the tic_gemm_tn_scratch slab + one reduce launch (1) | stream-K atomics (0)
-static int g_opt_tn_split_wgs = 1024;    // split-M weight-gradient kernels (128x128 tiles): workgroups aimed at (every split adds its tile to C with fp32 atomics)
+static int g_opt_tn_split_wgs = 1024;    // split-M weight-gradient kernels (128x128 tiles): MOST workgroups per launch (every split adds its tile to C with fp32 atomics)
+static int g_opt_tn_split_rows = 2048;   // ... rows of the reduction a workgroup is given, and ...
+static int g_opt_tn_split_min_wgs = 384; // ... FEWEST workgroups (tn_split below)
+static int g_opt_tn_slab_min_tiles = 8;  // single weight gradients: the 256x256 row-parts + slab route from this many 256x256 tiles on (below: split-M 128x128 kernel)
+// Row splits of the 128x128 weight-gradient kernels (1x1 and implicit 3x3 / 7x7 convolutions, small Linear layers): every split costs a
+// 64 KiB tile of fp32 atomics (1.3 TB/s chip-wide) and a prologue, a workgroup needs ~25-50 steps of 64 rows to amortise them, and the
+// chip wants >= ~1.5 workgroups per CU.  Measured over every convolution of ResNet-50 at 256 images and ResNet-152 at 80
+// (tools/resnet_conv_table.py with tn_split_wgs = 256 ... 2048, profiles/r03_conv_wgrad_routes.log): the best split keeps 1 600-3 600 rows
+// per workgroup with 384-1 024 workgroups in all; a fixed 1 024 (round 2) was right for 802 816-row layers and cost 20-60 % on the
+// 5 120 ... 81 920-row layers of ResNet-152 at the reference's batch.
+static int tn_split(int M, int tiles) {
+    int split = (M + g_opt_tn_split_rows - 1) / g_opt_tn_split_rows;
+    const int lo = (g_opt_tn_split_min_wgs + tiles - 1) / tiles, hi = g_opt_tn_split_wgs / tiles;
+    if (split < lo) split = lo;
+    if (split > hi) split = hi;
+    const int max_split = (M + 63) / 64;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    return split;
+}
 static int g_opt_tn_parts = -1;           // grouped dW without a phase-aligned split: -1 auto (256 / tiles equal row parts per tile), 0 never (flat stream-K), n forced
 static int g_opt_tn_streamk_min_steps = 128;   // grouped dW: fewest 64-row steps for which the stream-K split is chosen
 static int g_opt_ln_bwd_blocks = 512;    // LayerNorm backward: most blocks per launch
@@ -143,6 +162,10 @@ extern "C" int tic_set_option(const char* name, int value) {
         g_opt_nt_deep = value;
         return TIC_OK;
     }
+    if (name && !strcmp(name, "tn_slab_min_tiles") && value >= 1 && value <= 4096) {
+        g_opt_tn_slab_min_tiles = value;
+        return TIC_OK;
+    }
     if (name && !strcmp(name, "nt_fault") && (value == 0 || value == 1)) {
         g_opt_nt_fault = value;
         return TIC_OK;
@@ -160,6 +183,9 @@ extern "C" int tic_set_option(const char* name, int value) {
     TIC_KNOB("gemm_gm", g_opt_gemm_gm, 1, 256)
     TIC_KNOB("tn_slab", g_opt_tn_slab, 0, 1)
     TIC_KNOB("tn_split_wgs", g_opt_tn_split_wgs, 64, 8192)
+    TIC_KNOB("tn_split_rows", g_opt_tn_split_rows, 64, 1 << 20)
+    TIC_KNOB("tn_split_min_wgs", g_opt_tn_split_min_wgs, 1, 8192)
+
     TIC_KNOB("tn_streamk_min_steps", g_opt_tn_streamk_min_steps, 1, 1 << 20)
     TIC_KNOB("ln_bwd_blocks", g_opt_ln_bwd_blocks, 64, 65536)
     TIC_KNOB("ln_bwd_rows", g_opt_ln_bwd_rows, 1, 64)
@@ -406,7 +432,9 @@ extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, i
     TIC_REQUIRE(A && B && C, "gemm_tn: null operand");
     // long reductions over 256-aligned outputs (the 1x1-convolution weight gradients of ResNet: a handful of tiles, M up to 10^5
     // rows) go to the deep-pipelined 256x256 kernel through its stream-K split, which needs no minimum tile count
-    if (g_opt_gemm_tile != 128 && g_opt_tn_streamk && N % 256 == 0 && K % 256 == 0 && M >= 8192 &&
+    // (from 8 tiles on: with 4 -- a 256 <-> 1024 1x1 convolution -- 64 row parts of a 1 MiB output make 64 MiB of slab traffic and the
+    // split-M 128x128 kernel is 20-25 % faster: 40.6 / 43.7 against 52 us at 20 480 rows, 71 / 69 against 78 / 80 us at 50 176)
+    if (g_opt_gemm_tile != 128 && g_opt_tn_streamk && N % 256 == 0 && K % 256 == 0 && M >= 8192 && (long)(N / 256) * (K / 256) >= g_opt_tn_slab_min_tiles &&
         (long)(N / 256) * (K / 256) * ((M + 63) / 64) >= 256 && ((double)M + 320.0) * (N > K ? N : K) * 2.0 < 4294967296.0) {
         const void* a1[1] = {A};
         const void* b1[1] = {B};
@@ -419,10 +447,7 @@ extern "C" int tic_gemm_tn_bf16(const void* A, const void* B, float* C, int M, i
     TIC_REQUIRE(((double)M + 64.0) * (N > K ? N : K) * 2.0 < 4294967296.0, "gemm_tn: operand exceeds the 4 GiB buffer-resource range");
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     // split the M reduction so that ~4 workgroups per CU are in flight (256 CUs)
-    int split = (g_opt_tn_split_wgs + tiles - 1) / tiles;
-    const int max_split = (M + 63) / 64;
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
+    int split = tn_split(M, tiles);
     int m_per = ((M + split - 1) / split + 63) / 64 * 64;
     split = (M + m_per - 1) / m_per;
     GemmTnParams p;
@@ -951,10 +976,7 @@ extern "C" int tic_conv_igemm_wgrad(const void* dy, const void* x_nhwc, float* d
                 "conv_igemm_wgrad: tensor exceeds the 32-bit offset / 2^24 row range");
     const int M = (int)Ml;
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-    int split = (g_opt_tn_split_wgs + tiles - 1) / tiles;
-    const int max_split = (M + 63) / 64;
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
+    int split = tn_split(M, tiles);
     int m_per = ((M + split - 1) / split + 63) / 64 * 64;
     split = (M + m_per - 1) / m_per;
     GemmTnParams p;
