@@ -102,7 +102,11 @@ static int tn_split(int M, int tiles) {
     return split;
 }
 static int g_opt_tn_parts = -1;           // grouped dW without a phase-aligned split: -1 auto (256 / tiles equal row parts per tile), 0 never (flat stream-K), n forced
-static int g_opt_tn_streamk_min_steps = 128;   // grouped dW: fewest 64-row steps for which the stream-K split is chosen
+static int g_opt_tn_streamk_min_steps = 128;   // grouped dW: fewest 64-row steps for which the stream-K split is chosen when C is accumulated into ...
+static int g_opt_tn_streamk_min_steps_store = 352;   // ... and when it is stored (overwrite): the one-workgroup-per-tile form then has no read of C and no
+                                               // zeroing pass to pay for, and keeps winning up to ~110 images of ViT-L (tools/ab_step.py tn_streamk 1 0 in the
+                                               // fused step: 48 images 25.93 -> 24.84 ms, 64: 31.17 -> 30.59, 83: 36.36 -> 35.91, 100: 46.57 -> 46.26, 128: 55.59 <- 56.12)
+static int g_opt_tn_mfma16_min_steps = 256;    // stream-K launch: v_mfma_f32_16x16x32_bf16 from this many steps on (in the step: -0.5 ... -0.7 % at 64-128 images too)
 static int g_opt_ln_bwd_blocks = 512;    // LayerNorm backward: most blocks per launch
 static int g_opt_ln_bwd_rows = 2;        // LayerNorm backward: fewest rows per wave (bounds the number of dgamma / dbeta atomic rows)
 static int g_opt_gemm_big_tiles = 128;   // fewest 256x256 tiles for which the 256x256 NT kernel is chosen (gemm_tile = 0)
@@ -112,8 +116,8 @@ static int g_opt_gemm_stagger_groups = 2; // groups of first-round workgroups; g
 static int g_opt_gemm_stagger = -1;   // -1: auto (see gemm_nt), 0: off, n: s_sleep rounds; gemm256.h    // measurement only: see gemm256.h DBG
 static int g_opt_tn_streamk = 1;
 static int g_opt_tn_block = -1;   // tile-walk block width of the grouped dW launch: -1 auto (one XCD share per block), 0 row-major, n fixed
-static int g_opt_tn_mfma = 0;     // MFMA shape of the grouped dW stream-K launch: 0 auto (16x16x32 from 512 M steps per tile on: -1.7 % at M = 65 404,
-                                  // but +2..5 % at M = 12 608, tools/dw_ab.py tn_mfma 16 32), 16, 32
+static int g_opt_tn_mfma = 0;     // MFMA shape of the grouped dW stream-K launch: 0 auto (16x16x32 from g_opt_tn_mfma16_min_steps M steps per tile on: -1.7 % at
+                                  // M = 65 404; stand-alone it measured +2..5 % at M = 12 608 (tools/dw_ab.py tn_mfma 16 32), inside the step -0.7 %), 16, 32
 static int g_opt_tn_phase = 1;   // 1: phase-aligned stream-K split when the tile count allows; 0: always the flat split
 #if defined(TIC_SIM) || defined(TIC_MEASURE)
 static int g_opt_tn_waves = 8;   // experiment: 4 = the one-wave-per-SIMD form of the grouped dW tile (gemm_tn256.h tn256_tile_segment16_w4)
@@ -187,6 +191,8 @@ extern "C" int tic_set_option(const char* name, int value) {
     TIC_KNOB("tn_split_min_wgs", g_opt_tn_split_min_wgs, 1, 8192)
 
     TIC_KNOB("tn_streamk_min_steps", g_opt_tn_streamk_min_steps, 1, 1 << 20)
+    TIC_KNOB("tn_streamk_min_steps_store", g_opt_tn_streamk_min_steps_store, 1, 1 << 20)
+    TIC_KNOB("tn_mfma16_min_steps", g_opt_tn_mfma16_min_steps, 1, 1 << 20)
     TIC_KNOB("ln_bwd_blocks", g_opt_ln_bwd_blocks, 64, 65536)
     TIC_KNOB("ln_bwd_rows", g_opt_ln_bwd_rows, 1, 64)
     TIC_KNOB("gemm_big_tiles", g_opt_gemm_big_tiles, 1, 65536)
@@ -515,7 +521,7 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
         // short reductions (< 128 steps of 64 rows = fewer than ~42 images of ViT-L tokens): one workgroup per full-M tile; the stream-K
         // split's partial tiles cost more than the idle quarter of the CUs (tools/small_batch_bench.py: 71 vs 100 us at M = 1576,
         // 166 vs 175 at M = 6304, 331 vs 288 at M = 12608)
-        const bool streamk = g_opt_tn_streamk && (force256 || g_opt_tn_streamk > 1 || nsteps >= g_opt_tn_streamk_min_steps);
+        const bool streamk = g_opt_tn_streamk && (force256 || g_opt_tn_streamk > 1 || nsteps >= (overwrite ? g_opt_tn_streamk_min_steps_store : g_opt_tn_streamk_min_steps));
         if (streamk && (long)t * nsteps >= shares) {
             if (overwrite) TIC_TRY(zero_all());   // partial tiles are ADDED
             // phase-aligned split when the tiles divide over the 8 XCDs and the tail workgroups get whole tiles
@@ -569,7 +575,7 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
                 TIC_LAUNCH(gemm_tn256_streamk_w4_kernel, grid_wg, 256, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
             } else
 #endif
-            if (g_opt_tn_mfma == 32 || (g_opt_tn_mfma == 0 && nsteps < 512)) {
+            if (g_opt_tn_mfma == 32 || (g_opt_tn_mfma == 0 && nsteps < g_opt_tn_mfma16_min_steps)) {
                 TIC_RT_MAX_LDS(gemm_tn256_streamk_mfma32_kernel, G256_LDS_BYTES);
                 TIC_LAUNCH(gemm_tn256_streamk_mfma32_kernel, grid_wg, 512, G256_LDS_BYTES, stream, gp, nsteps, s_main, tpx, tail_each);
             } else {
