@@ -618,6 +618,10 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
 }
 
 // ---- LayerNorm -------------------------------------------------------------------------------------
+// non-temporal accesses to the fp32 residual stream (stream_nt bit 0) only when that stream is larger than the 256 MB Infinity Cache:
+// below, the next kernel finds it there and the hint costs 0.4-1.0 % of the step (tools/ab_step.py stream_nt 13 12: 64 images 31.02 vs
+// 30.77 ms, 100: 45.72 vs 45.27, 128: 54.55 vs 54.29, 166: 65.93 vs 65.84; 332 images = 268 MB: 127.38 vs 127.43)
+static bool ln_nt(int rows, int D) { return (g_opt_nt & 1) && (size_t)rows * D * 4 >= ((size_t)256 << 20); }
 extern "C" int tic_layernorm_bwd_ex(const void* dy_bf16, const float* x, long stride, const float* gamma, const float* mean,
                                     const float* rstd, const float* dres, float* dx, void* dxb_bf16, float* dgamma,
                                     float* dbeta, float* colsum, int rows, int D, tic_stream_t stream);
@@ -632,7 +636,7 @@ extern "C" int tic_layernorm_fwd(const float* x, long in_stride, const float* ga
     const int nv = (D + 255) / 256, grid = ln_grid(rows);
 #define TIC_LN_FWD(NV)                                                                                                                   \
     do {                                                                                                                                 \
-        if (g_opt_nt & 1) TIC_LAUNCH((ln_fwd_kernel<NV, true>), grid, 256, 0, stream, x, in_stride, gamma, beta, (bf16_t*)y_bf16, mean, rstd, rows, D, eps); \
+        if (ln_nt(rows, D)) TIC_LAUNCH((ln_fwd_kernel<NV, true>), grid, 256, 0, stream, x, in_stride, gamma, beta, (bf16_t*)y_bf16, mean, rstd, rows, D, eps); \
         else TIC_LAUNCH((ln_fwd_kernel<NV, false>), grid, 256, 0, stream, x, in_stride, gamma, beta, (bf16_t*)y_bf16, mean, rstd, rows, D, eps);          \
     } while (0)
     if (nv == 1) TIC_LN_FWD(1); else if (nv == 2) TIC_LN_FWD(2); else if (nv == 3) TIC_LN_FWD(3); else TIC_LN_FWD(4);
@@ -658,7 +662,7 @@ extern "C" int tic_layernorm_bwd_ex(const void* dy_bf16, const float* x, long st
     const size_t lds = (size_t)3 * 4 * D * 4;
 #define TIC_LN_BWD(NV)                                                                                                                   \
     do {                                                                                                                                 \
-        if (g_opt_nt & 1) TIC_LAUNCH((ln_bwd_kernel<NV, true>), grid, 256, lds, stream, (const bf16_t*)dy_bf16, x, stride, gamma, mean, rstd, dres, dx, (bf16_t*)dxb_bf16, dgamma, dbeta, colsum, rows, D); \
+        if (ln_nt(rows, D)) TIC_LAUNCH((ln_bwd_kernel<NV, true>), grid, 256, lds, stream, (const bf16_t*)dy_bf16, x, stride, gamma, mean, rstd, dres, dx, (bf16_t*)dxb_bf16, dgamma, dbeta, colsum, rows, D); \
         else TIC_LAUNCH((ln_bwd_kernel<NV, false>), grid, 256, lds, stream, (const bf16_t*)dy_bf16, x, stride, gamma, mean, rstd, dres, dx, (bf16_t*)dxb_bf16, dgamma, dbeta, colsum, rows, D);          \
     } while (0)
     if (nv == 1) TIC_LN_BWD(1); else if (nv == 2) TIC_LN_BWD(2); else if (nv == 3) TIC_LN_BWD(3); else TIC_LN_BWD(4);
