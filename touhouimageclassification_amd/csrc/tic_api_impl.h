@@ -518,9 +518,10 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
         gp.nprob = nprob; gp.M = M; gp.total_tiles = t;
         const int nsteps = (M + 63) / 64;
         const long shares = g_opt_tn_streamk == 1 ? 256 : g_opt_tn_streamk;   // one share per CU by default
-        // short reductions (< 128 steps of 64 rows = fewer than ~42 images of ViT-L tokens): one workgroup per full-M tile; the stream-K
-        // split's partial tiles cost more than the idle quarter of the CUs (tools/small_batch_bench.py: 71 vs 100 us at M = 1576,
-        // 166 vs 175 at M = 6304, 331 vs 288 at M = 12608)
+        // short reductions: one workgroup per full-M tile; the stream-K split's partial tiles (fp32 atomics) cost more than the idle quarter
+        // of the CUs.  When C is accumulated into: below 128 steps of 64 rows (~42 images of ViT-L tokens; tools/small_batch_bench.py: 71 vs
+        // 100 us at M = 1576, 166 vs 175 at M = 6304, 331 vs 288 at M = 12608); when C is stored (no read of C, no zeroing): below 352
+        // steps (measured inside the step, see g_opt_tn_streamk_min_steps_store)
         const bool streamk = g_opt_tn_streamk && (force256 || g_opt_tn_streamk > 1 || nsteps >= (overwrite ? g_opt_tn_streamk_min_steps_store : g_opt_tn_streamk_min_steps));
         if (streamk && (long)t * nsteps >= shares) {
             if (overwrite) TIC_TRY(zero_all());   // partial tiles are ADDED
