@@ -218,8 +218,11 @@ class TicViTForImageClassification(nn.Module):
         head_only = not any(p.requires_grad for n, p in params.items() if n.startswith("vit.embeddings") or n.startswith("vit.layers"))
         trainable = [p for p in params.values() if p.requires_grad]
         if any(p.grad is None for p in trainable):
-            # zero_grad(set_to_none=True) (torch default) dropped the views: start from a clean buffer
-            e.grads.zero_()
+            # zero_grad(set_to_none=True) (torch default) dropped the views: start from a clean buffer.  When EVERY gradient was dropped and the
+            # whole network is trained, nothing in the buffer is to be kept: clear only the ranges that accumulate and let this backward store
+            # the weight-matrix gradients (engine.zero_grads) -- what the fused step does; otherwise zero everything and accumulate.
+            fresh = not head_only and all(p.grad is None for p in trainable) and len(trainable) == len(params)
+            e.zero_grads(dlogits.shape[0], keep_matrices=fresh)
         hook = None
         if self._bucket_hook is not None:
             user = self._bucket_hook
