@@ -265,6 +265,24 @@ __global__ void __launch_bounds__(256) adamw_rest_kernel(float* __restrict__ p, 
     }
 }
 
+// up to 4 fp32 arrays cleared by ONE launch (the C matrices of a grouped weight-gradient launch whose route adds partial tiles: four
+// hipMemsetAsync calls cost ~6 us each on the stream, this ~8 us for the 50 MB of a ViT-L block).  grid (blocks, n arrays); n4 = float4 count
+struct ZeroMany {
+    float* p[4];
+    long n4[4];
+};
+__global__ void __launch_bounds__(256) zero_many_kernel(ZeroMany z) {
+    float* p = z.p[0];
+    long n4 = z.n4[0];
+#pragma unroll
+    for (int g = 1; g < 4; ++g)
+        if (TIC_BID_Y == g) {
+            p = z.p[g];
+            n4 = z.n4[g];
+        }
+    for (long i = (long)TIC_BID_X * 256 + TIC_TID; i < n4; i += (long)TIC_NBLK_X * 256) *reinterpret_cast<f32x4*>(p + i * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // g = 0 outside the weight-matrix ranges: the gradients that ACCUMULATE (bias / LayerNorm column sums, embeddings, head) start from
 // zero while the matrix gradients, which the backward stores whole, are not touched
 __global__ void __launch_bounds__(256) zero_gaps_kernel(float* __restrict__ g, RestGaps z) {

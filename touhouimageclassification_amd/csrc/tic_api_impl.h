@@ -488,7 +488,18 @@ static int gemm_tn_group_impl(int nprob, const void* const* A, const void* const
         tiles += (N[g] / 256) * (K[g] / 256);
     }
     auto zero_all = [&]() -> int {
-        for (int g = 0; g < nprob; ++g) TIC_RT_MEMSET(C[g], 0, (size_t)N[g] * K[g] * 4, stream);
+        bool one_launch = nprob <= 4;
+        for (int g = 0; g < nprob; ++g) one_launch = one_launch && ((size_t)N[g] * K[g]) % 4 == 0 && TIC_ALIGNED16(C[g]);
+        if (!one_launch) {
+            for (int g = 0; g < nprob; ++g) TIC_RT_MEMSET(C[g], 0, (size_t)N[g] * K[g] * 4, stream);
+            return TIC_OK;
+        }
+        ZeroMany z;
+        for (int g = 0; g < 4; ++g) {
+            z.p[g] = g < nprob ? C[g] : nullptr;
+            z.n4[g] = g < nprob ? (long)((size_t)N[g] * K[g] / 4) : 0;
+        }
+        TIC_LAUNCH(zero_many_kernel, dim3(512, (unsigned)nprob), 256, 0, stream, z);
         return TIC_OK;
     };
     if (ok256 && g_opt_gemm_tile != 128 && (force256 || g_opt_gemm_tile == 256 || (tiles >= 96 && M >= 512))) {
